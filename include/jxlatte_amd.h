@@ -1,0 +1,256 @@
+/*
+ * jxlatte_amd.h -- C-ABI of the MI355X (gfx950) transform back-end for jxlatte.
+ *
+ * The reference (Traneptora/jxlatte, pure Java) has no FFI; this header is the
+ * boundary *cut* at the call sites of its per-frame transform stage
+ * (J/ = java/com/traneptora/jxlatte/ in the reference tree):
+ *
+ *   J/frame/Frame.java:361-374      decodePassGroups VarDCT tail -> PassGroup.invertVarDCT
+ *   J/frame/Frame.java:427          globalModular.applyTransforms()
+ *   J/frame/Frame.java:430-461      modular->buffer, Gab, EPF
+ *   J/JXLCodestreamDecoder.java:637 performColorTransforms (invertXYB)
+ *   J/io/PNGWriter.java:65,105-111  transfer (PQ/sRGB) + castToIntWithMax
+ *
+ * Plain pointers and sizes only. Every function returns a jxl_status
+ * (0 = OK, negative = error); no exception crosses the ABI. The two reference
+ * exception families map 1:1: InvalidBitstreamException -> JXL_ERR_INVALID_BITSTREAM,
+ * UnsupportedOperationException -> JXL_ERR_UNSUPPORTED.
+ *
+ * Layout everywhere: planar, row-major, 32-bit elements, channel order X,Y,B
+ * (buffer index 0,1,2 as in Frame.buffer[]). "cell" = 8x8 px, "tile" = 64x64 px
+ * (chroma-from-luma granularity), "group" = 256x256 px, "LF group" = 2048x2048 px.
+ */
+#ifndef JXLATTE_AMD_H
+#define JXLATTE_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t jxl_status;
+#define JXL_OK                      0
+#define JXL_ERR_INVALID_ARGUMENT  (-1)
+#define JXL_ERR_INVALID_BITSTREAM (-2) /* J/io/InvalidBitstreamException.java:5 */
+#define JXL_ERR_UNSUPPORTED       (-3) /* UnsupportedOperationException, PassGroup.java:326-327 */
+#define JXL_ERR_DEVICE            (-4)
+#define JXL_ERR_OOM               (-5)
+#define JXL_ERR_STATE             (-6) /* IllegalStateException (call order) */
+
+/* TransformType.type values, J/frame/vardct/TransformType.java:10-36 */
+#define JXL_NUM_TRANSFORM_TYPES 27
+/* number of quant-weight parameter sets, HFGlobal.weights[17][3][][] (HFGlobal.java:191) */
+#define JXL_NUM_WEIGHT_SETS 17
+
+/* output stage selector (PNGWriter ctor: tf = hdr ? PQ : sRGB; bit depth 8/16) */
+#define JXL_TRANSFER_NONE 0 /* stop after invertXYB: linear float */
+#define JXL_TRANSFER_PQ   1 /* TransferFunction.TF_PQ.fromLinear, TransferFunction.java:83-87 */
+#define JXL_TRANSFER_SRGB 2 /* TransferFunction.TF_SRGB.fromLinearF, :39-44 */
+#define JXL_OUT_F32 0       /* float planes */
+#define JXL_OUT_U16 1       /* ImageBuffer.castToIntWithMax(65535), ImageBuffer.java:129-147 */
+#define JXL_OUT_U8  2       /* ImageBuffer.castToIntWithMax(255) */
+
+/* stage mask bits for jxl_vardct_params.stages */
+#define JXL_STAGE_IDCT 1u  /* dequant + CfL + LLF + inverse transforms (PassGroup.invertVarDCT) */
+#define JXL_STAGE_GAB  2u  /* Frame.performGabConvolution */
+#define JXL_STAGE_EPF  4u  /* Frame.performEdgePreservingFilter */
+#define JXL_STAGE_XYB  8u  /* OpsinInverseMatrix.invertXYB */
+#define JXL_STAGE_OUT 16u  /* transfer + int quantisation */
+
+typedef struct jxl_ctx jxl_ctx;
+
+/* Frame-constant parameters of one VarDCT frame. All float fields are produced by
+ * the host exactly as the reference computes them (file:line given per field). */
+typedef struct jxl_vardct_params {
+    int32_t width;   /* Frame.getPaddedFrameSize().width  (Frame.java:924-941), multiple of 8 */
+    int32_t height;  /* Frame.getPaddedFrameSize().height */
+    uint32_t stages; /* JXL_STAGE_* mask; gab/epf/xyb bits are ANDed with the flags below */
+
+    /* HFCoefficients.dequantizeHFCoefficients (HFCoefficients.java:267-275) */
+    float scale_factor[3];      /* {gs*(float)pow(0.8,xqm-2), gs, gs*(float)pow(0.8,bqm-2)}, gs = 65536f/globalScale */
+    float quant_bias[3];        /* OpsinInverseMatrix.quantBias */
+    float quant_bias_numerator; /* OpsinInverseMatrix.quantBiasNumerator */
+
+    /* HFCoefficients.chromaFromLuma (:146-192), LFChannelCorrelation */
+    float base_corr_x;
+    float base_corr_b;
+    int32_t color_factor;
+
+    /* RestorationFilter (RestorationFilter.java:12-79) */
+    int32_t gab;         /* restorationFilter.gab */
+    float gab_w1[3];     /* gab1Weights */
+    float gab_w2[3];     /* gab2Weights */
+    int32_t epf_iters;   /* epfIterations 0..3 */
+    float global_scale_f;    /* 65536f / lfGlobal.globalScale (Frame.java:554) */
+    float epf_sharp_lut[8];  /* epfSharpLut, already multiplied by epfQuantMul (:78) */
+    float epf_channel_scale[3];
+    float epf_pass0_sigma_scale;
+    float epf_pass2_sigma_scale;
+    float epf_border_sad_mul;
+
+    /* OpsinInverseMatrix (OpsinInverseMatrix.java:105-142) */
+    int32_t xyb;             /* matrix != null in performColorTransforms */
+    float opsin_matrix[9];   /* adapted matrix (getMatrix), NOT yet scaled by 255/intensityTarget */
+    float opsin_bias[3];
+    float cbrt_opsin_bias[3];/* (float)Math.cbrt(opsinBias[c]) (:83) */
+    float intensity_target;
+
+    int32_t transfer;   /* JXL_TRANSFER_* */
+    int32_t out_format; /* JXL_OUT_* */
+} jxl_vardct_params;
+
+/* One LF group's side information, in the reference's own per-LF-group shape
+ * (HFMetadata.java:16-52, LFCoefficients.dequantLFCoeff). Host pointers. */
+typedef struct jxl_lfgroup_desc {
+    int32_t lfg_y, lfg_x;       /* Frame.getLFGroupLocation: position in LF-group units */
+    int32_t cells_h, cells_w;   /* LFGroup.size in 8x8 cells (<= 256) */
+    const uint8_t* dct_select;  /* [cells_h][cells_w] TransformType.type of the covering varblock */
+    const int32_t* hf_mul;      /* [cells_h][cells_w] hfMultiplier */
+    const int32_t* sharpness;   /* [cells_h][cells_w] hfStreamBuffer[3] */
+    const int32_t* x_from_y;    /* [ceil(cells_h/8)][ceil(cells_w/8)] hfStreamBuffer[0] */
+    const int32_t* b_from_y;    /* same shape, hfStreamBuffer[1] */
+    const int32_t* block_yx;    /* blockList: n_blocks x {y,x} in cells, placement order */
+    int32_t n_blocks;
+    const float* lf[3];         /* dequantLFCoeff[c] [cells_h][cells_w] */
+} jxl_lfgroup_desc;
+
+/* SqueezeParam (J/frame/modular/SqueezeParam.java) */
+typedef struct jxl_squeeze_param {
+    int32_t horizontal;
+    int32_t in_place;
+    int32_t begin_c;
+    int32_t num_c;
+} jxl_squeeze_param;
+
+/* A modular channel plane (ModularChannel.buffer + size). Host pointer. */
+typedef struct jxl_channel {
+    int32_t width;
+    int32_t height;
+    int32_t* data; /* [height][width], may be NULL when width*height == 0 */
+} jxl_channel;
+
+/* ---- context ------------------------------------------------------------------ */
+/* One ctx = one HIP device + one stream + a device arena reused across frames.
+ * Single-threaded like a JXLDecoder instance; distinct ctxs are independent. */
+jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out);
+void       jxl_ctx_destroy(jxl_ctx* ctx);
+const char* jxl_last_error(const jxl_ctx* ctx);
+const char* jxl_version(void);
+jxl_status jxl_ctx_synchronize(jxl_ctx* ctx);
+/* HIP stream handle (hipStream_t) the ctx launches on; for event timing by callers. */
+void*      jxl_ctx_stream(jxl_ctx* ctx);
+
+/* ---- VarDCT frame path: replaces Frame.decodePassGroups tail .. performColorTransforms */
+/* call order: begin_frame, set_weights, set_lfgroup* , put_group*, (run | finish_frame) */
+jxl_status jxl_vardct_begin_frame(jxl_ctx* ctx, const jxl_vardct_params* params);
+/* HFGlobal.weights (already reciprocal, HFGlobal.java:421-431): 17 sets x 3 channels, each
+ * matrixHeight x matrixWidth row-major; offs[p*3+c] = element offset of set p channel c in w. */
+jxl_status jxl_vardct_set_weights(jxl_ctx* ctx, const float* w, size_t n_floats, const int32_t* offs /*[51]*/);
+jxl_status jxl_vardct_set_lfgroup(jxl_ctx* ctx, const jxl_lfgroup_desc* lfg);
+/* quantizedCoeffs of one (pass, group) (HFCoefficients.java:43,68): q[c] is [gh][gw] with row
+ * stride[c] elements; gh,gw = Frame.getGroupSize(group). pass > 0 accumulates
+ * (PassGroup.java:174-200). */
+jxl_status jxl_vardct_put_group(jxl_ctx* ctx, int32_t pass, int32_t group,
+                                const int32_t* const q[3], const int32_t stride[3]);
+/* Launch every enabled stage on the ctx stream; inputs are resident after put_group.
+ * Asynchronous: returns after enqueue. Re-runnable (inputs are not consumed). */
+jxl_status jxl_vardct_run(jxl_ctx* ctx);
+/* run + synchronize + copy result planes to the host. out[c]: width*height elements of
+ * float (JXL_OUT_F32) / uint16 / uint8, row stride = out_stride elements. */
+jxl_status jxl_vardct_finish_frame(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
+/* copy the last run's result planes (device) to host without re-running */
+jxl_status jxl_vardct_read_output(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
+/* device-to-device copy of the result into caller-owned device memory (e.g. an RCCL send
+ * buffer): dst = 3 planes back to back, width*height elements each. Async on the ctx stream. */
+jxl_status jxl_vardct_copy_output_device(jxl_ctx* ctx, void* dst_device);
+/* bytes of one output element for the configured out_format */
+int32_t    jxl_vardct_out_elem_size(const jxl_ctx* ctx);
+/* number of kernel launches the last jxl_vardct_run enqueued (diagnostics) */
+int32_t    jxl_vardct_last_launch_count(const jxl_ctx* ctx);
+/* time the last jxl_vardct_run's dominant kernel(s) with HIP events on the ctx stream:
+ * which = 0 whole run, 1 IDCT stage, 2 restoration+colour stage. ms out. */
+jxl_status jxl_vardct_last_stage_ms(jxl_ctx* ctx, int32_t which, float* ms);
+jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* ctx, int32_t on);
+
+/* ---- stage-level entry points (host planes in, host planes out; synchronous) --- */
+/* One per reference function on the path; used by the parity tests. */
+
+/* MathHelper.inverseDCT2D (MathHelper.java:96-122) on one h x w block. */
+jxl_status jxl_stage_idct2d(jxl_ctx* ctx, const float* src, float* dst, int32_t h, int32_t w, int32_t transposed);
+/* MathHelper.forwardDCT2D (MathHelper.java:124-136). */
+jxl_status jxl_stage_fdct2d(jxl_ctx* ctx, const float* src, float* dst, int32_t h, int32_t w);
+/* Frame.performGabConvolution (Frame.java:505-542). */
+jxl_status jxl_stage_gab(jxl_ctx* ctx, const float* const in[3], float* const out[3],
+                         int32_t height, int32_t width, const float w1[3], const float w2[3]);
+/* Frame.performEdgePreservingFilter (Frame.java:544-636). inv_sigma: [ceil(h/8)][ceil(w/8)]
+ * map for VarDCT, or NULL to use the constant inv_sigma_modular (Frame.java:573-575). */
+jxl_status jxl_stage_epf(jxl_ctx* ctx, const float* const in[3], float* const out[3],
+                         int32_t height, int32_t width, int32_t iterations,
+                         const float* inv_sigma, float inv_sigma_modular,
+                         const float channel_scale[3], float pass0_sigma_scale,
+                         float pass2_sigma_scale, float border_sad_mul);
+/* inverse-sigma map of Frame.java:552-571 from hfMul + sharpness cell maps. */
+jxl_status jxl_stage_epf_sigma(jxl_ctx* ctx, const int32_t* hf_mul, const int32_t* sharpness,
+                               int32_t bh, int32_t bw, float global_scale_f,
+                               const float sharp_lut[8], float* inv_sigma);
+/* OpsinInverseMatrix.invertXYB (OpsinInverseMatrix.java:105-142), in place on planes[3]. */
+jxl_status jxl_stage_xyb(jxl_ctx* ctx, float* const planes[3], int64_t n,
+                         const float matrix[9], const float opsin_bias[3],
+                         const float cbrt_opsin_bias[3], float intensity_target);
+/* YCbCr branch of performColorTransforms (JXLCodestreamDecoder.java:270-281), in place. */
+jxl_status jxl_stage_ycbcr(jxl_ctx* ctx, float* const planes[3], int64_t n);
+/* JXLImage.transferInPlace + ImageBuffer.castToInt0: transfer = JXL_TRANSFER_*,
+ * max_value = 0 keeps float output in out_f, else writes clamped ints to out_i. */
+jxl_status jxl_stage_transfer(jxl_ctx* ctx, const float* in, int64_t n, int32_t transfer,
+                              int32_t max_value, float* out_f, int32_t* out_i);
+/* ModularChannel.inverseHorizontalSqueeze / inverseVerticalSqueeze
+ * (ModularChannel.java:361-413). out is (h) x (aw+rw) resp. (ah+rh) x (w). */
+jxl_status jxl_stage_inv_hsqueeze(jxl_ctx* ctx, const int32_t* avg, int32_t aw, const int32_t* res, int32_t rw,
+                                  int32_t h, int32_t* out);
+jxl_status jxl_stage_inv_vsqueeze(jxl_ctx* ctx, const int32_t* avg, int32_t ah, const int32_t* res, int32_t rh,
+                                  int32_t w, int32_t* out);
+/* RCT branch of ModularStream.applyTransforms (ModularStream.java:255-326): in place on
+ * v[3] of n samples; rct_type = permutation*7 + type. On return v[] holds the planes in
+ * output channel order (the permutation is applied). */
+jxl_status jxl_stage_rct(jxl_ctx* ctx, int32_t* const v[3], int64_t n, int32_t rct_type);
+/* Frame.decodeFrame modular->buffer (Frame.java:430-455) for one output channel:
+ * out = scale * (a + b) (b may be NULL) as float. */
+jxl_status jxl_stage_modular_to_float(jxl_ctx* ctx, const int32_t* a, const int32_t* b, int64_t n,
+                                      float scale, float* out);
+
+/* ---- Modular path: replaces ModularStream.applyTransforms squeeze/RCT branches ---- */
+/* Default squeeze parameter list of ModularStream.java:110-131 for a channel list whose
+ * first nb_meta channels are meta channels. Returns the count (<= cap) or a negative status. */
+int32_t    jxl_modular_default_squeeze_params(const int32_t* widths, const int32_t* heights, int32_t n_channels,
+                                              int32_t nb_meta, jxl_squeeze_param* out, int32_t cap);
+/* Forward shape replay of ModularStream.java:137-167: given the n_channels image channels,
+ * produce the encoded channel list's shapes (count returned; <= cap). */
+int32_t    jxl_modular_squeezed_shapes(const int32_t* widths, const int32_t* heights, int32_t n_channels,
+                                       const jxl_squeeze_param* sp, int32_t n_sp,
+                                       int32_t* out_w, int32_t* out_h, int32_t cap);
+/* Upload the encoded channel list (averages + residuals as decoded by the host) and the
+ * transform to undo. n_out = number of channels after the inverse. rct_type < 0 = no RCT,
+ * otherwise applied on channels rct_begin..+2 after the squeeze. */
+jxl_status jxl_modular_begin(jxl_ctx* ctx, const jxl_channel* chans, int32_t n_chans,
+                             const jxl_squeeze_param* sp, int32_t n_sp,
+                             int32_t rct_type, int32_t rct_begin);
+/* enqueue the inverse steps (asynchronous, re-runnable) */
+jxl_status jxl_modular_run(jxl_ctx* ctx);
+/* number / shape of result channels */
+int32_t    jxl_modular_out_count(const jxl_ctx* ctx);
+jxl_status jxl_modular_out_shape(const jxl_ctx* ctx, int32_t idx, int32_t* w, int32_t* h);
+/* synchronize + copy result channel idx to host */
+jxl_status jxl_modular_read_channel(jxl_ctx* ctx, int32_t idx, int32_t* dst);
+/* begin + run + read of all channels: out[i].data must hold out w*h elements */
+jxl_status jxl_modular_apply(jxl_ctx* ctx, const jxl_channel* chans, int32_t n_chans,
+                             const jxl_squeeze_param* sp, int32_t n_sp,
+                             int32_t rct_type, int32_t rct_begin,
+                             jxl_channel* out, int32_t n_out);
+int32_t    jxl_modular_last_launch_count(const jxl_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXLATTE_AMD_H */
