@@ -22,7 +22,11 @@ typedef struct jxl_tt_info {
     uint16_t ph, pw; /* pixelHeight, pixelWidth */
 } jxl_tt_info;
 
+#ifdef __cplusplus
+static constexpr jxl_tt_info JXL_TT[27] = {
+#else
 static const jxl_tt_info JXL_TT[27] = {
+#endif
     {0, 0, 0, JXL_METHOD_DCT, 8, 8},          /* DCT8 */
     {1, 1, 1, JXL_METHOD_HORNUSS, 8, 8},      /* HORNUSS */
     {2, 2, 1, JXL_METHOD_DCT2, 8, 8},         /* DCT2 */

@@ -1,0 +1,60 @@
+"""Build libjxlatte_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m jxlatte_amd.build [--force]
+
+Flags that matter for parity: -ffp-contract=off (no FMA contraction; the reference rounds every
+multiply and add separately), no fast-math, default correctly-rounded f32 division and preserved
+f32 denormals.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libjxlatte_amd.so")
+SOURCES = ["k_idct.hip", "k_restore.hip", "k_restore_fused.hip", "k_modular.hip", "host.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _deps():
+    inc = os.path.join(HERE, "..", "include")
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    d += [os.path.join(inc, f) for f in os.listdir(inc)]
+    return d
+
+
+def build(force=False, verbose=False):
+    newest = max(os.path.getmtime(p) for p in _deps())
+    objs = []
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            jobs.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-6000:]))
+            return r.stderr
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for err in ex.map(run, jobs):
+                if verbose and err.strip():
+                    print(err)
+    if jobs or not os.path.exists(SO):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

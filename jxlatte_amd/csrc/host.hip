@@ -1,0 +1,1089 @@
+// Host side of libjxlatte_amd.so: the C-ABI of include/jxlatte_amd.h, the per-frame device arena,
+// varblock binning and the launch sequence. gfx950 only; there is no CPU fallback -- every entry
+// point needs a HIP device and fails with JXL_ERR_DEVICE otherwise.
+#include "jxl_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace jxl;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (bytes == 0) bytes = 16;
+        if (hipMalloc(&p, bytes) != hipSuccess) return false;
+        cap = bytes;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ModOp {
+    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy
+    const int32_t* a;
+    const int32_t* b;
+    int32_t* o;
+    int32_t *v0, *v1, *v2;
+    int adim, rdim, other;  // hsq: aw, rw, h; vsq: ah, rh, w
+    int64_t n;
+    int type;
+};
+
+struct ModChan {
+    int w, h;
+    int32_t* d;
+    bool original;
+};
+
+}  // namespace
+
+struct jxl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    DevBuf lut;
+
+    // ---- VarDCT frame state
+    bool frame_open = false;
+    bool tables_dirty = true;
+    bool have_weights = false;
+    jxl_vardct_params p{};
+    int W = 0, H = 0, bw = 0, bh = 0, tw = 0, th = 0;
+    DevBuf coeff[3], lf[3], hf_mul, sharp, xfy, bfy, weights, planeA[3], planeB[3], outbuf[3], inv_sigma, blocks, items,
+        group_tmp, bad_flag;
+    int32_t woffs[51]{};
+    std::vector<int32_t> h_hf_mul, h_sharp, h_xfy, h_bfy;
+    std::vector<uint8_t> h_sel;
+    std::vector<float> h_lf[3];
+    std::vector<std::vector<DevBlock>> lfg_blocks;  // per LF group, reference order, frame coordinates
+    std::vector<uint8_t> lfg_set;
+    // binned work
+    int n_small_items = 0, small_items_off = 0;
+    struct MedLaunch { int type, items_off, n_items; };
+    std::vector<MedLaunch> med;
+    int large_first = 0, large_count = 0;
+    std::vector<DevBlock> h_blocks;
+    // results
+    void* result[3] = {nullptr, nullptr, nullptr};
+    int result_elem = 4;
+    int last_launches = 0;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+
+    // ---- Modular state
+    std::vector<DevBuf> mod_bufs;
+    std::vector<ModOp> mod_ops;
+    std::vector<ModChan> mod_out;
+    int mod_launches = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+jxl_status fail(jxl_ctx* ctx, jxl_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_err = buf;
+    return st;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? JXL_ERR_OOM : JXL_ERR_DEVICE, "%s: %s", #expr,     \
+                        hipGetErrorString(e_));                                                             \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// cosineLut of MathHelper.java:17-30, all sizes back to back (size s = 1<<l at lut_off(l))
+void build_lut(std::vector<float>& t) {
+    t.assign(kLutTotal, 0.0f);
+    const double root2 = std::sqrt(2.0);
+    const double pi = 3.14159265358979323846;  // Math.PI
+    for (int l = 0; l < 9; l++) {
+        const int s = 1 << l;
+        float* o = t.data() + lut_off(l);
+        for (int n = 0; n < s - 1; n++)
+            for (int k = 0; k < s; k++) o[n * s + k] = (float)(root2 * std::cos(pi * (n + 1) * (k + 0.5) / s));
+    }
+}
+
+jxl_status bind(jxl_ctx* ctx) {
+    if (!ctx) return fail(nullptr, JXL_ERR_INVALID_ARGUMENT, "null ctx");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return JXL_OK;
+}
+
+__global__ void k_accumulate2d(int32_t* dst, int64_t dpitch, const int32_t* src, int gw, int gh) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= gw || y >= gh) return;
+    int32_t* d = dst + (int64_t)y * dpitch + x;
+    *d = (int32_t)((uint32_t)*d + (uint32_t)src[(int64_t)y * gw + x]);  // PassGroup.java:174-200
+}
+
+bool is_small(int t) { return JXL_TT[t].ph == 8 && JXL_TT[t].pw == 8; }
+bool is_large(int t) { return JXL_TT[t].ph >= 128 || JXL_TT[t].pw >= 128; }
+
+// Bin the varblocks and compute the CfL cache-order masks; upload side tables.
+jxl_status finalize_tables(jxl_ctx* c) {
+    if (!c->tables_dirty) return JXL_OK;
+    const int lrs = ceil_div(c->W, 2048), lcs = ceil_div(c->H, 2048);
+    for (int i = 0; i < lrs * lcs; i++)
+        if (!c->lfg_set[i]) return fail(c, JXL_ERR_STATE, "LF group %d was never set", i);
+    if (!c->have_weights) return fail(c, JXL_ERR_STATE, "quant weights were never set");
+    const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
+    // reference visiting order: groups in raster order (Frame.java:367-373), inside a group the LF group's
+    // blockList order filtered by the group (HFCoefficients.java:76-85)
+    std::vector<std::vector<DevBlock>> per_group((size_t)grs * gcs);
+    for (int li = 0; li < lrs * lcs; li++) {
+        for (const DevBlock& b : c->lfg_blocks[li]) {
+            const int g = (b.cy >> 5) * grs + (b.cx >> 5);
+            per_group[g].push_back(b);
+        }
+    }
+    std::vector<int32_t> stamp((size_t)c->th * c->tw, -1);
+    std::vector<DevBlock> sm[JXL_NUM_TRANSFORM_TYPES];
+    for (int g = 0; g < grs * gcs; g++) {
+        for (DevBlock b : per_group[g]) {
+            const int ph = JXL_TT[b.type].ph, pw = JXL_TT[b.type].pw;
+            const int py0 = b.cy * 8, px0 = b.cx * 8;
+            if (py0 + ph > c->H || px0 + pw > c->W)
+                return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock (%d,%d) type %u leaves the frame", b.cy, b.cx, b.type);
+            const int ty0 = py0 >> 6, tx0 = px0 >> 6, ty1 = (py0 + ph - 1) >> 6, tx1 = (px0 + pw - 1) >> 6;
+            if (ty1 - ty0 > 4 || tx1 - tx0 > 4) return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock spans too many tiles");
+            uint32_t mask = 0;
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    const bool origin_inside = ty * 64 >= py0 && tx * 64 >= px0;  // (< py0+ph, px0+pw by the loop bounds)
+                    if (origin_inside) stamp[(size_t)ty * c->tw + tx] = g;
+                    else if (stamp[(size_t)ty * c->tw + tx] != g) mask |= 1u << ((ty - ty0) * 5 + (tx - tx0));
+                }
+            b.cfl_zero = mask;
+            sm[b.type].push_back(b);
+        }
+    }
+    // layout: [small types..., medium types..., large types...]
+    c->h_blocks.clear();
+    std::vector<WorkItem> items;
+    c->med.clear();
+    c->small_items_off = 0;
+    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
+        if (!is_small(t) || sm[t].empty()) continue;
+        const uint32_t first = (uint32_t)c->h_blocks.size();
+        c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
+        for (uint32_t o = 0; o < sm[t].size(); o += 64)
+            items.push_back(WorkItem{(uint32_t)t, first + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
+    }
+    c->n_small_items = (int)items.size();
+    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
+        if (is_small(t) || is_large(t) || sm[t].empty()) continue;
+        const uint32_t first = (uint32_t)c->h_blocks.size();
+        c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
+        const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
+        jxl_ctx::MedLaunch ml{t, (int)items.size(), 0};
+        for (uint32_t o = 0; o < sm[t].size(); o += nb)
+            items.push_back(WorkItem{(uint32_t)t, first + o, (uint32_t)std::min<size_t>(nb, sm[t].size() - o)});
+        ml.n_items = (int)items.size() - ml.items_off;
+        c->med.push_back(ml);
+    }
+    c->large_first = (int)c->h_blocks.size();
+    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+        if (is_large(t)) c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
+    c->large_count = (int)c->h_blocks.size() - c->large_first;
+
+    if (!c->blocks.ensure(sizeof(DevBlock) * std::max<size_t>(1, c->h_blocks.size())) ||
+        !c->items.ensure(sizeof(WorkItem) * std::max<size_t>(1, items.size())))
+        return fail(c, JXL_ERR_OOM, "device allocation failed (block tables)");
+    const size_t nc = (size_t)c->bh * c->bw, nt = (size_t)c->th * c->tw;
+    if (!c->h_blocks.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->blocks.p, c->h_blocks.data(), sizeof(DevBlock) * c->h_blocks.size(), hipMemcpyHostToDevice, c->stream));
+    if (!items.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->items.p, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->hf_mul.p, c->h_hf_mul.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sharp.p, c->h_sharp.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->xfy.p, c->h_xfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->bfy.p, c->h_bfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
+    for (int ch = 0; ch < 3; ch++)
+        HIP_TRY(c, hipMemcpyAsync(c->lf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
+    c->tables_dirty = false;
+    return JXL_OK;
+}
+
+void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
+    f.width = c->W; f.height = c->H; f.bw = c->bw; f.bh = c->bh; f.tw = c->tw; f.th = c->th;
+    for (int ch = 0; ch < 3; ch++) {
+        f.coeff[ch] = c->coeff[ch].as<int32_t>();
+        f.lf[ch] = c->lf[ch].as<float>();
+        f.scale_factor[ch] = c->p.scale_factor[ch];
+        f.quant_bias[ch] = c->p.quant_bias[ch];
+    }
+    f.hf_mul = c->hf_mul.as<int32_t>();
+    f.sharpness = c->sharp.as<int32_t>();
+    f.x_from_y = c->xfy.as<int32_t>();
+    f.b_from_y = c->bfy.as<int32_t>();
+    f.weights = c->weights.as<float>();
+    memcpy(f.woffs, c->woffs, sizeof f.woffs);
+    f.lut = c->lut.as<float>();
+    f.quant_bias_numerator = c->p.quant_bias_numerator;
+    f.base_corr_x = c->p.base_corr_x;
+    f.base_corr_b = c->p.base_corr_b;
+    f.color_factor_f = (float)c->p.color_factor;
+}
+
+const float kStepMultiplier = 1.65f * 4.0f * (1.0f - (float)std::sqrt(0.5));  // Frame.java:545
+
+EpfParams make_epf(const float cs[3], float pass0, float pass2, float border, int iter, float inv_sigma_modular) {
+    EpfParams e;
+    for (int i = 0; i < 3; i++) e.channel_scale[i] = cs[i];
+    e.sigma_scale = iter == 0 ? kStepMultiplier * pass0 : iter == 2 ? kStepMultiplier * pass2 : kStepMultiplier;  // :592-598
+    e.border_sad_mul = border;
+    e.inv_sigma_modular = inv_sigma_modular;
+    return e;
+}
+
+XybParams make_xyb(const float m[9], const float ob[3], const float cob[3], float intensity_target) {
+    XybParams x;
+    const float itScale = 255.0f / intensity_target;  // OpsinInverseMatrix.java:108
+    for (int i = 0; i < 9; i++) x.sm[i] = m[i] * itScale;
+    for (int i = 0; i < 3; i++) {
+        x.ob[i] = ob[i];
+        x.cob[i] = -cob[i];
+    }
+    return x;
+}
+
+int out_elem_size(int fmt) { return fmt == JXL_OUT_U16 ? 2 : fmt == JXL_OUT_U8 ? 1 : 4; }
+
+}  // namespace
+
+namespace {
+struct Tmp {
+    std::vector<void*> v;
+    ~Tmp() { for (void* p : v) (void)hipFree(p); }
+    template <typename T>
+    T* up(const T* host, size_t n) {
+        void* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(16, n * sizeof(T))) != hipSuccess) return nullptr;
+        v.push_back(d);
+        if (host && n && hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return (T*)d;
+    }
+};
+jxl_status finish(jxl_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "device error: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+}  // namespace
+
+
+// ================================================================================================
+extern "C" {
+
+const char* jxl_version(void) { return "jxlatte_amd 0.1 (gfx950)"; }
+
+const char* jxl_last_error(const jxl_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
+    if (!out) return fail(nullptr, JXL_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, JXL_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(nullptr, JXL_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, n);
+    jxl_ctx* c = new jxl_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, JXL_ERR_DEVICE, "cannot initialise device %d", device);
+    }
+    std::vector<float> lut;
+    build_lut(lut);
+    if (!c->lut.ensure(sizeof(float) * lut.size()) ||
+        hipMemcpy(c->lut.p, lut.data(), sizeof(float) * lut.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        !c->bad_flag.ensure(sizeof(int))) {
+        jxl_ctx_destroy(c);
+        return fail(nullptr, JXL_ERR_DEVICE, "cannot upload the cosine LUT");
+    }
+    for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
+    *out = c;
+    return JXL_OK;
+}
+
+void jxl_ctx_destroy(jxl_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf* all[] = {&c->lut, &c->hf_mul, &c->sharp, &c->xfy, &c->bfy, &c->weights, &c->inv_sigma, &c->blocks, &c->items,
+                     &c->group_tmp, &c->bad_flag};
+    for (DevBuf* b : all) b->release();
+    for (int i = 0; i < 3; i++) {
+        c->coeff[i].release(); c->lf[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
+    }
+    for (auto& b : c->mod_bufs) b.release();
+    for (int i = 0; i < 4; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+jxl_status jxl_ctx_synchronize(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return JXL_OK;
+}
+
+void* jxl_ctx_stream(jxl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- VarDCT frame ---------------------------------------------------------------------------------
+jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!p) return fail(c, JXL_ERR_INVALID_ARGUMENT, "params is null");
+    if (p->width <= 0 || p->height <= 0 || (p->width & 7) || (p->height & 7))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "padded frame size %dx%d must be positive multiples of 8", p->width, p->height);
+    if (p->epf_iters < 0 || p->epf_iters > 3) return fail(c, JXL_ERR_INVALID_BITSTREAM, "epfIterations %d", p->epf_iters);
+    if (p->out_format < 0 || p->out_format > 2 || p->transfer < 0 || p->transfer > 2)
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output stage selector");
+    c->p = *p;
+    c->W = p->width; c->H = p->height;
+    c->bw = c->W / 8; c->bh = c->H / 8;
+    c->tw = ceil_div(c->bw, 8); c->th = ceil_div(c->bh, 8);
+    const size_t npx = (size_t)c->W * c->H, nc = (size_t)c->bw * c->bh, nt = (size_t)c->tw * c->th;
+    bool ok = true;
+    for (int i = 0; i < 3; i++) {
+        ok = ok && c->coeff[i].ensure(4 * npx) && c->planeA[i].ensure(4 * npx) && c->planeB[i].ensure(4 * npx) &&
+             c->lf[i].ensure(4 * nc);
+        if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
+    }
+    ok = ok && c->hf_mul.ensure(4 * nc) && c->sharp.ensure(4 * nc) && c->xfy.ensure(4 * nt) && c->bfy.ensure(4 * nt) &&
+         c->inv_sigma.ensure(4 * nc) && c->group_tmp.ensure(4 * 256 * 256);
+    if (!ok) return fail(c, JXL_ERR_OOM, "device allocation failed for a %dx%d frame", c->W, c->H);
+    for (int i = 0; i < 3; i++) {
+        HIP_TRY(c, hipMemsetAsync(c->coeff[i].p, 0, 4 * npx, c->stream));   // new int[sY][sX] (HFCoefficients.java:68)
+        HIP_TRY(c, hipMemsetAsync(c->planeA[i].p, 0, 4 * npx, c->stream));  // frame buffer starts zeroed (ImageBuffer ctor)
+        c->h_lf[i].assign(nc, 0.0f);
+    }
+    c->h_hf_mul.assign(nc, 1);
+    c->h_sharp.assign(nc, 0);
+    c->h_sel.assign(nc, 255);
+    c->h_xfy.assign(nt, 0);
+    c->h_bfy.assign(nt, 0);
+    const int nl = ceil_div(c->W, 2048) * ceil_div(c->H, 2048);
+    c->lfg_blocks.assign(nl, {});
+    c->lfg_set.assign(nl, 0);
+    c->tables_dirty = true;
+    c->frame_open = true;
+    c->ev_valid = false;
+    c->result[0] = c->result[1] = c->result[2] = nullptr;
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_set_weights(jxl_ctx* c, const float* w, size_t n_floats, const int32_t* offs) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!w || !offs || n_floats == 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null weights");
+    for (int pi = 0; pi < JXL_NUM_WEIGHT_SETS; pi++) {
+        int mh = 0, mw = 0;
+        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+            if (JXL_TT[t].param_index == pi && !(JXL_TT[t].ph > JXL_TT[t].pw)) { mh = jxl_tt_mh(&JXL_TT[t]); mw = jxl_tt_mw(&JXL_TT[t]); break; }
+        for (int ch = 0; ch < 3; ch++) {
+            const int32_t o = offs[pi * 3 + ch];
+            if (o < 0 || (size_t)o + (size_t)mh * mw > n_floats) return fail(c, JXL_ERR_INVALID_ARGUMENT, "weight offset %d out of range", o);
+        }
+    }
+    if (!c->weights.ensure(sizeof(float) * n_floats)) return fail(c, JXL_ERR_OOM, "device allocation failed (weights)");
+    HIP_TRY(c, hipMemcpy(c->weights.p, w, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+    memcpy(c->woffs, offs, sizeof c->woffs);
+    c->have_weights = true;
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    if (!g || !g->dct_select || !g->hf_mul || !g->sharpness || !g->x_from_y || !g->b_from_y || !g->lf[0] || !g->lf[1] || !g->lf[2] ||
+        (g->n_blocks > 0 && !g->block_yx))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "null pointer in LF group descriptor");
+    const int lrs = ceil_div(c->W, 2048), lcs = ceil_div(c->H, 2048);
+    if (g->lfg_x < 0 || g->lfg_x >= lrs || g->lfg_y < 0 || g->lfg_y >= lcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group position out of range");
+    const int y0 = g->lfg_y * 256, x0 = g->lfg_x * 256;
+    const int eh = std::min(256, c->bh - y0), ew = std::min(256, c->bw - x0);
+    if (g->cells_h != eh || g->cells_w != ew)
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group (%d,%d) must be %dx%d cells, got %dx%d", g->lfg_y, g->lfg_x, eh, ew, g->cells_h, g->cells_w);
+    const int gth = ceil_div(eh, 8), gtw = ceil_div(ew, 8);
+    for (int y = 0; y < eh; y++) {
+        for (int x = 0; x < ew; x++) {
+            const size_t d = (size_t)(y0 + y) * c->bw + x0 + x, s = (size_t)y * ew + x;
+            c->h_hf_mul[d] = g->hf_mul[s];
+            c->h_sharp[d] = g->sharpness[s];
+            c->h_sel[d] = g->dct_select[s];
+            for (int ch = 0; ch < 3; ch++) c->h_lf[ch][d] = g->lf[ch][s];
+        }
+    }
+    for (int y = 0; y < gth; y++)
+        for (int x = 0; x < gtw; x++) {
+            const size_t d = (size_t)(g->lfg_y * 32 + y) * c->tw + g->lfg_x * 32 + x;
+            c->h_xfy[d] = g->x_from_y[y * gtw + x];
+            c->h_bfy[d] = g->b_from_y[y * gtw + x];
+        }
+    std::vector<DevBlock>& bl = c->lfg_blocks[g->lfg_y * lrs + g->lfg_x];
+    bl.clear();
+    bl.reserve(g->n_blocks);
+    for (int i = 0; i < g->n_blocks; i++) {
+        const int by = g->block_yx[2 * i], bx = g->block_yx[2 * i + 1];
+        if (by < 0 || bx < 0 || by >= eh || bx >= ew) return fail(c, JXL_ERR_INVALID_BITSTREAM, "block %d at (%d,%d) outside its LF group", i, by, bx);
+        const int t = g->dct_select[(size_t)by * ew + bx];
+        if (t > 26) return fail(c, JXL_ERR_INVALID_BITSTREAM, "Invalid Transform Type: %d", t);  // HFMetadata.java:46-47
+        bl.push_back(DevBlock{(uint16_t)(y0 + by), (uint16_t)(x0 + bx), (uint32_t)t, 0u});
+    }
+    c->lfg_set[g->lfg_y * lrs + g->lfg_x] = 1;
+    c->tables_dirty = true;
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const int32_t* const q[3], const int32_t stride[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
+    if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
+    const int gy = group / grs, gx = group % grs;  // Frame.getGroupLocation (Frame.java:883)
+    const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);  // getGroupSize (:905)
+    for (int ch = 0; ch < 3; ch++) {
+        if (!q[ch] || stride[ch] < gw) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
+        int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)(gy * 256) * c->W + gx * 256;
+        if (pass == 0) {
+            HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->W * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gw * 4, gh, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(c, hipMemcpy2DAsync(c->group_tmp.p, (size_t)gw * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gw * 4, gh, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_accumulate2d, dim3(ceil_div(gw, 64), ceil_div(gh, 4)), dim3(256), 0, c->stream, dst, (int64_t)c->W,
+                               c->group_tmp.as<int32_t>(), gw, gh);
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller's buffer is pageable and may be reused
+    }
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* c, int32_t on) {
+    if (!c) return JXL_ERR_INVALID_ARGUMENT;
+    c->timing = on != 0;
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_run(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    st = finalize_tables(c);
+    if (st) return st;
+    const jxl_vardct_params& p = c->p;
+    hipStream_t s = c->stream;
+    int launches = 0;
+    float* A[3] = {c->planeA[0].as<float>(), c->planeA[1].as<float>(), c->planeA[2].as<float>()};
+    float* B[3] = {c->planeB[0].as<float>(), c->planeB[1].as<float>(), c->planeB[2].as<float>()};
+    if (c->timing) (void)hipEventRecord(c->ev[0], s);
+    if (p.stages & JXL_STAGE_IDCT) {
+        DevFrame f;
+        fill_dev_frame(c, f);
+        const DevBlock* blocks = c->blocks.as<DevBlock>();
+        const WorkItem* items = c->items.as<WorkItem>();
+        if (c->n_small_items > 0) {
+            launch_idct_small(f, blocks, items + c->small_items_off, c->n_small_items, A, s);
+            launches++;
+        }
+        for (const auto& ml : c->med) {
+            launch_idct_medium_type(f, blocks, items + ml.items_off, ml.n_items, ml.type, A, s);
+            launches++;
+        }
+        if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
+    }
+    if (c->timing) (void)hipEventRecord(c->ev[1], s);
+    float** cur = A;
+    float** oth = B;
+    const bool do_gab = (p.stages & JXL_STAGE_GAB) && p.gab;
+    const bool do_epf = (p.stages & JXL_STAGE_EPF) && p.epf_iters > 0;
+    const bool do_xyb = (p.stages & JXL_STAGE_XYB) && p.xyb;
+    const bool do_out = (p.stages & JXL_STAGE_OUT) && (p.transfer != JXL_TRANSFER_NONE || p.out_format != JXL_OUT_F32);
+    if (do_epf) {
+        // sharpness range check of Frame.java:565-566 (host side: the maps came through the host)
+        for (int32_t v : c->h_sharp)
+            if (v < 0 || v > 7) return fail(c, JXL_ERR_INVALID_BITSTREAM, "Invalid EPF Sharpness: %d", v);
+    }
+    bool fused = false;
+    if (do_gab || do_epf || do_xyb || do_out) {
+        RestoreParams rp{};
+        rp.gab = do_gab; rp.epf_iters = do_epf ? p.epf_iters : 0; rp.xyb = do_xyb;
+        rp.transfer = do_out ? p.transfer : JXL_TRANSFER_NONE;
+        rp.max_value = do_out ? (p.out_format == JXL_OUT_U16 ? 65535 : p.out_format == JXL_OUT_U8 ? 255 : 0) : 0;
+        rp.out_elem = do_out ? out_elem_size(p.out_format) : 4;
+        for (int i = 0; i < 3; i++) {
+            const float mult = 1.0f / (1.0f + 4.0f * (p.gab_w1[i] + p.gab_w2[i]));  // Frame.java:510-517
+            rp.gab_base[i] = mult; rp.gab_adj[i] = p.gab_w1[i] * mult; rp.gab_diag[i] = p.gab_w2[i] * mult;
+            rp.epf[i] = make_epf(p.epf_channel_scale, p.epf_pass0_sigma_scale, p.epf_pass2_sigma_scale, p.epf_border_sad_mul, i, 0.0f);
+        }
+        rp.xybp = make_xyb(p.opsin_matrix, p.opsin_bias, p.cbrt_opsin_bias, p.intensity_target);
+        rp.global_scale_f = p.global_scale_f;
+        memcpy(rp.sharp_lut, p.epf_sharp_lut, sizeof rp.sharp_lut);
+        void* dst[3];
+        for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
+        const float* src[3] = {cur[0], cur[1], cur[2]};
+        fused = launch_restore_fused(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, s);
+        if (fused) {
+            launches++;
+            for (int i = 0; i < 3; i++) c->result[i] = dst[i];
+            c->result_elem = rp.out_elem;
+        }
+    }
+    if (!fused) {
+        if (do_gab) {
+            const float* src[3] = {cur[0], cur[1], cur[2]};
+            launch_gab(src, oth, c->H, c->W, p.gab_w1, p.gab_w2, s);
+            std::swap(cur, oth);
+            launches++;
+        }
+        if (do_epf) {
+            launch_epf_sigma(c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), c->bh, c->bw, p.global_scale_f, p.epf_sharp_lut,
+                             c->inv_sigma.as<float>(), c->bad_flag.as<int>(), s);
+            launches++;
+            for (int i = 0; i < 3; i++) {  // Frame.java:583-587
+                if (i == 0 && p.epf_iters < 3) continue;
+                if (i == 2 && p.epf_iters < 2) break;
+                const float* src[3] = {cur[0], cur[1], cur[2]};
+                launch_epf_iter(src, oth, c->H, c->W, i, c->inv_sigma.as<float>(),
+                                make_epf(p.epf_channel_scale, p.epf_pass0_sigma_scale, p.epf_pass2_sigma_scale, p.epf_border_sad_mul, i, 0.0f), s);
+                std::swap(cur, oth);
+                launches++;
+            }
+        }
+        if (do_xyb) {
+            launch_xyb(cur, (int64_t)c->W * c->H, make_xyb(p.opsin_matrix, p.opsin_bias, p.cbrt_opsin_bias, p.intensity_target), s);
+            launches++;
+        }
+        if (do_out) {
+            const int maxv = p.out_format == JXL_OUT_U16 ? 65535 : p.out_format == JXL_OUT_U8 ? 255 : 0;
+            const int es = out_elem_size(p.out_format);
+            for (int i = 0; i < 3; i++) {
+                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer, maxv, c->outbuf[i].p, es, s);
+                c->result[i] = c->outbuf[i].p;
+                launches++;
+            }
+            c->result_elem = es;
+        } else {
+            for (int i = 0; i < 3; i++) c->result[i] = cur[i];
+            c->result_elem = 4;
+        }
+    }
+    if (c->timing) {
+        (void)hipEventRecord(c->ev[2], s);
+        c->ev_valid = true;
+    }
+    c->last_launches = launches;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_last_stage_ms(jxl_ctx* c, int32_t which, float* ms) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!ms || !c->ev_valid) return fail(c, JXL_ERR_STATE, "enable stage timing and run first");
+    HIP_TRY(c, hipEventSynchronize(c->ev[2]));
+    const int a = which == 2 ? 1 : 0, b = which == 1 ? 1 : 2;
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    return JXL_OK;
+}
+
+int32_t jxl_vardct_out_elem_size(const jxl_ctx* c) { return c ? c->result_elem : 0; }
+int32_t jxl_vardct_last_launch_count(const jxl_ctx* c) { return c ? c->last_launches : 0; }
+
+jxl_status jxl_vardct_read_output(jxl_ctx* c, void* const out[3], int64_t out_stride) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->result[0]) return fail(c, JXL_ERR_STATE, "nothing has been run");
+    if (!out || out_stride < c->W) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output planes");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t es = (size_t)c->result_elem;
+    for (int i = 0; i < 3; i++) {
+        if (!out[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane %d", i);
+        HIP_TRY(c, hipMemcpy2D(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H, hipMemcpyDeviceToHost));
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "device error: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_finish_frame(jxl_ctx* c, void* const out[3], int64_t out_stride) {
+    jxl_status st = jxl_vardct_run(c);
+    if (st) return st;
+    return jxl_vardct_read_output(c, out, out_stride);
+}
+
+jxl_status jxl_vardct_copy_output_device(jxl_ctx* c, void* dst_device) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->result[0] || !dst_device) return fail(c, JXL_ERR_STATE, "nothing has been run");
+    const size_t bytes = (size_t)c->W * c->H * c->result_elem;
+    for (int i = 0; i < 3; i++)
+        HIP_TRY(c, hipMemcpyAsync((char*)dst_device + i * bytes, c->result[i], bytes, hipMemcpyDeviceToDevice, c->stream));
+    return JXL_OK;
+}
+
+// ---- stage-level entries -----------------------------------------------------------------------------
+jxl_status jxl_stage_idct2d(jxl_ctx* c, const float* src, float* dst, int32_t h, int32_t w, int32_t transposed) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    auto pow2 = [](int v) { return v >= 1 && v <= 256 && (v & (v - 1)) == 0; };
+    if (!src || !dst || !pow2(h) || !pow2(w)) return fail(c, JXL_ERR_INVALID_ARGUMENT, "idct2d: sizes must be powers of two <= 256");
+    Tmp t;
+    float* ds = t.up(src, (size_t)h * w);
+    float* dd = t.up<float>(nullptr, (size_t)h * w);
+    if (!ds || !dd) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_idct2d_single(ds, dd, h, w, transposed, c->lut.as<float>(), c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(dst, dd, sizeof(float) * h * w, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_fdct2d(jxl_ctx* c, const float* src, float* dst, int32_t h, int32_t w) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    auto pow2 = [](int v) { return v >= 1 && v <= 256 && (v & (v - 1)) == 0; };
+    if (!src || !dst || !pow2(h) || !pow2(w)) return fail(c, JXL_ERR_INVALID_ARGUMENT, "fdct2d: sizes must be powers of two <= 256");
+    Tmp t;
+    float* ds = t.up(src, (size_t)h * w);
+    float* dd = t.up<float>(nullptr, (size_t)h * w);
+    if (!ds || !dd) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_fdct2d_single(ds, dd, h, w, c->lut.as<float>(), c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(dst, dd, sizeof(float) * h * w, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_gab(jxl_ctx* c, const float* const in[3], float* const out[3], int32_t height, int32_t width,
+                         const float w1[3], const float w2[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!in || !out || height <= 0 || width <= 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "gab: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)height * width;
+    const float* di[3];
+    float* dd[3];
+    for (int i = 0; i < 3; i++) {
+        di[i] = t.up(in[i], n);
+        dd[i] = t.up<float>(nullptr, n);
+        if (!di[i] || !dd[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    launch_gab(di, dd, height, width, w1, w2, c->stream);
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpy(out[i], dd[i], 4 * n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_epf_sigma(jxl_ctx* c, const int32_t* hf_mul, const int32_t* sharpness, int32_t bh, int32_t bw,
+                               float global_scale_f, const float sharp_lut[8], float* inv_sigma) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!hf_mul || !sharpness || !inv_sigma || bh <= 0 || bw <= 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "epf_sigma: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)bh * bw;
+    int32_t* dh = t.up(hf_mul, n);
+    int32_t* ds = t.up(sharpness, n);
+    float* dv = t.up<float>(nullptr, n);
+    if (!dh || !ds || !dv) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    HIP_TRY(c, hipMemsetAsync(c->bad_flag.p, 0, sizeof(int), c->stream));
+    launch_epf_sigma(dh, ds, bh, bw, global_scale_f, sharp_lut, dv, c->bad_flag.as<int>(), c->stream);
+    if ((st = finish(c))) return st;
+    int bad = 0;
+    HIP_TRY(c, hipMemcpy(&bad, c->bad_flag.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) return fail(c, JXL_ERR_INVALID_BITSTREAM, "Invalid EPF Sharpness");  // Frame.java:565-566
+    HIP_TRY(c, hipMemcpy(inv_sigma, dv, 4 * n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_epf(jxl_ctx* c, const float* const in[3], float* const out[3], int32_t height, int32_t width,
+                         int32_t iterations, const float* inv_sigma, float inv_sigma_modular, const float channel_scale[3],
+                         float pass0_sigma_scale, float pass2_sigma_scale, float border_sad_mul) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!in || !out || height <= 0 || width <= 0 || iterations < 0 || iterations > 3) return fail(c, JXL_ERR_INVALID_ARGUMENT, "epf: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)height * width;
+    float* a[3];
+    float* b[3];
+    for (int i = 0; i < 3; i++) {
+        a[i] = t.up(in[i], n);
+        b[i] = t.up<float>(nullptr, n);
+        if (!a[i] || !b[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    float* dsig = nullptr;
+    if (inv_sigma) {
+        dsig = t.up(inv_sigma, (size_t)((height + 7) >> 3) * ((width + 7) >> 3));
+        if (!dsig) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    float** cur = a;
+    float** oth = b;
+    for (int i = 0; i < 3 && iterations > 0; i++) {
+        if (i == 0 && iterations < 3) continue;
+        if (i == 2 && iterations < 2) break;
+        const float* src[3] = {cur[0], cur[1], cur[2]};
+        launch_epf_iter(src, oth, height, width, i, dsig,
+                        make_epf(channel_scale, pass0_sigma_scale, pass2_sigma_scale, border_sad_mul, i, inv_sigma_modular), c->stream);
+        std::swap(cur, oth);
+    }
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpy(out[i], cur[i], 4 * n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_xyb(jxl_ctx* c, float* const planes[3], int64_t n, const float matrix[9], const float opsin_bias[3],
+                         const float cbrt_opsin_bias[3], float intensity_target) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!planes || n < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "xyb: bad arguments");  // "Can only XYB on 3 channels"
+    Tmp t;
+    float* d[3];
+    for (int i = 0; i < 3; i++) {
+        d[i] = t.up(planes[i], (size_t)n);
+        if (!d[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    launch_xyb(d, n, make_xyb(matrix, opsin_bias, cbrt_opsin_bias, intensity_target), c->stream);
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpy(planes[i], d[i], 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_ycbcr(jxl_ctx* c, float* const planes[3], int64_t n) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!planes || n < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "ycbcr: bad arguments");
+    Tmp t;
+    float* d[3];
+    for (int i = 0; i < 3; i++) {
+        d[i] = t.up(planes[i], (size_t)n);
+        if (!d[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    launch_ycbcr(d, n, c->stream);
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpy(planes[i], d[i], 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_transfer(jxl_ctx* c, const float* in, int64_t n, int32_t transfer, int32_t max_value, float* out_f,
+                              int32_t* out_i) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!in || n < 0 || transfer < 0 || transfer > 2 || max_value < 0 || (max_value > 0 ? !out_i : !out_f))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "transfer: bad arguments");
+    Tmp t;
+    float* di = t.up(in, (size_t)n);
+    int32_t* dout = t.up<int32_t>(nullptr, (size_t)n);
+    if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_transfer(di, n, transfer, max_value, dout, 4, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(max_value > 0 ? (void*)out_i : (void*)out_f, dout, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_inv_hsqueeze(jxl_ctx* c, const int32_t* avg, int32_t aw, const int32_t* res, int32_t rw, int32_t h, int32_t* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    // shape checks of ModularChannel.java:363-366 -> IllegalArgumentException
+    if (aw < 0 || rw < 0 || h < 0 || (aw != rw && aw != rw + 1) || !out) return fail(c, JXL_ERR_INVALID_ARGUMENT, "Corrupted squeeze transform");
+    Tmp t;
+    int32_t* da = t.up(avg, (size_t)aw * h);
+    int32_t* dr = t.up(res, (size_t)rw * h);
+    int32_t* dout = t.up<int32_t>(nullptr, (size_t)(aw + rw) * h);
+    if (!da || !dr || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_inv_hsqueeze(da, aw, dr, rw, h, dout, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, dout, 4 * (size_t)(aw + rw) * h, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_inv_vsqueeze(jxl_ctx* c, const int32_t* avg, int32_t ah, const int32_t* res, int32_t rh, int32_t w, int32_t* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    // ModularChannel.java:391-394 -> IllegalStateException
+    if (ah < 0 || rh < 0 || w < 0 || (ah != rh && ah != rh + 1) || !out) return fail(c, JXL_ERR_STATE, "Corrupted squeeze transform");
+    Tmp t;
+    int32_t* da = t.up(avg, (size_t)ah * w);
+    int32_t* dr = t.up(res, (size_t)rh * w);
+    int32_t* dout = t.up<int32_t>(nullptr, (size_t)(ah + rh) * w);
+    if (!da || !dr || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_inv_vsqueeze(da, ah, dr, rh, w, dout, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, dout, 4 * (size_t)(ah + rh) * w, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+static const int kPermutationLut[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {2, 1, 0}};  // ModularStream.java:35-38
+
+jxl_status jxl_stage_rct(jxl_ctx* c, int32_t* const v[3], int64_t n, int32_t rct_type) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!v || n < 0 || rct_type < 0 || rct_type >= 42) return fail(c, JXL_ERR_INVALID_ARGUMENT, "rct: bad arguments");
+    Tmp t;
+    int32_t* d[3];
+    for (int i = 0; i < 3; i++) {
+        d[i] = t.up(v[i], (size_t)n);
+        if (!d[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    launch_rct(d[0], d[1], d[2], n, rct_type % 7, c->stream);
+    if ((st = finish(c))) return st;
+    const int perm = rct_type / 7;
+    for (int j = 0; j < 3; j++)  // channels.set(start + permutationLut[permutation][j], v[j])
+        HIP_TRY(c, hipMemcpy(v[kPermutationLut[perm][j]], d[j], 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_modular_to_float(jxl_ctx* c, const int32_t* a, const int32_t* b, int64_t n, float scale, float* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!a || !out || n < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "modular_to_float: bad arguments");
+    Tmp t;
+    int32_t* da = t.up(a, (size_t)n);
+    int32_t* db = b ? t.up(b, (size_t)n) : nullptr;
+    float* dd = t.up<float>(nullptr, (size_t)n);
+    if (!da || (b && !db) || !dd) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_modular_to_float(da, db, n, scale, dd, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, dd, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+// ---- Modular ----------------------------------------------------------------------------------------
+int32_t jxl_modular_default_squeeze_params(const int32_t* widths, const int32_t* heights, int32_t n_channels, int32_t nb_meta,
+                                           jxl_squeeze_param* out, int32_t cap) {
+    // ModularStream.java:110-131
+    if (!widths || !heights || !out || n_channels < 0 || nb_meta < 0) return JXL_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    const int first = nb_meta, count = n_channels - first;
+    if (count <= 0) return 0;
+    auto push = [&](int h, int ip, int b, int num) {
+        if (n >= cap) return false;
+        out[n++] = jxl_squeeze_param{h, ip, b, num};
+        return true;
+    };
+    int sw = widths[0], sh = heights[0];
+    if (count > 2 && sw == widths[first + 1] && sh == heights[first + 1]) {
+        if (!push(1, 0, first + 1, 2) || !push(0, 0, first + 1, 2)) return JXL_ERR_INVALID_ARGUMENT;
+    }
+    if (sh >= sw && sh > 8) {
+        if (!push(0, 1, first, count)) return JXL_ERR_INVALID_ARGUMENT;
+        sh = (sh + 1) / 2;
+    }
+    while (sw > 8 || sh > 8) {
+        if (sw > 8) {
+            if (!push(1, 1, first, count)) return JXL_ERR_INVALID_ARGUMENT;
+            sw = (sw + 1) / 2;
+        }
+        if (sh > 8) {
+            if (!push(0, 1, first, count)) return JXL_ERR_INVALID_ARGUMENT;
+            sh = (sh + 1) / 2;
+        }
+    }
+    return n;
+}
+
+int32_t jxl_modular_squeezed_shapes(const int32_t* widths, const int32_t* heights, int32_t n_channels, const jxl_squeeze_param* sp,
+                                    int32_t n_sp, int32_t* out_w, int32_t* out_h, int32_t cap) {
+    // ModularStream.java:134-167
+    if (!widths || !heights || !out_w || !out_h || n_channels < 0 || n_channels > cap || (n_sp > 0 && !sp)) return JXL_ERR_INVALID_ARGUMENT;
+    std::vector<std::pair<int, int>> ch;  // (w, h)
+    for (int i = 0; i < n_channels; i++) ch.emplace_back(widths[i], heights[i]);
+    for (int j = 0; j < n_sp; j++) {
+        const int begin = sp[j].begin_c, end = begin + sp[j].num_c - 1;
+        if (begin < 0 || end >= (int)ch.size()) return JXL_ERR_INVALID_BITSTREAM;
+        const int offset = sp[j].in_place ? end + 1 : (int)ch.size();
+        for (int k = begin; k <= end; k++) {
+            const int r = offset + k - begin;
+            std::pair<int, int> res;
+            if (sp[j].horizontal) {
+                const int w = ch[k].first;
+                ch[k].first = (w + 1) / 2;
+                res = {w / 2, ch[k].second};
+            } else {
+                const int h = ch[k].second;
+                ch[k].second = (h + 1) / 2;
+                res = {ch[k].first, h / 2};
+            }
+            ch.insert(ch.begin() + r, res);
+        }
+    }
+    if ((int)ch.size() > cap) return JXL_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < ch.size(); i++) {
+        out_w[i] = ch[i].first;
+        out_h[i] = ch[i].second;
+    }
+    return (int32_t)ch.size();
+}
+
+jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_chans, const jxl_squeeze_param* sp, int32_t n_sp,
+                             int32_t rct_type, int32_t rct_begin) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (n_chans < 0 || (n_chans > 0 && !chans) || (n_sp > 0 && !sp) || rct_type >= 42) return fail(c, JXL_ERR_INVALID_ARGUMENT, "modular: bad arguments");
+    for (auto& b : c->mod_bufs) b.release();
+    c->mod_bufs.clear();
+    c->mod_ops.clear();
+    c->mod_out.clear();
+    auto alloc = [&](size_t n_elems) -> int32_t* {
+        c->mod_bufs.emplace_back();
+        if (!c->mod_bufs.back().ensure(4 * std::max<size_t>(1, n_elems))) return nullptr;
+        return c->mod_bufs.back().as<int32_t>();
+    };
+    std::vector<ModChan> ch;
+    for (int i = 0; i < n_chans; i++) {
+        if (chans[i].width < 0 || chans[i].height < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "negative channel size");
+        const size_t n = (size_t)chans[i].width * chans[i].height;
+        if (n && !chans[i].data) return fail(c, JXL_ERR_INVALID_ARGUMENT, "channel %d has no data", i);
+        int32_t* d = alloc(n);
+        if (!d) return fail(c, JXL_ERR_OOM, "device allocation failed (modular channel)");
+        if (n) HIP_TRY(c, hipMemcpy(d, chans[i].data, 4 * n, hipMemcpyHostToDevice));
+        ch.push_back(ModChan{chans[i].width, chans[i].height, d, true});
+    }
+    // ModularStream.applyTransforms, SQUEEZE branch (ModularStream.java:229-254)
+    for (int j = n_sp - 1; j >= 0; j--) {
+        const int begin = sp[j].begin_c, end = begin + sp[j].num_c - 1;
+        const int n = (int)ch.size();
+        const int offset = sp[j].in_place ? end + 1 : n + begin - end - 1;
+        if (begin < 0 || end < begin || end >= n || offset < 0 || offset + (end - begin) >= n)
+            return fail(c, JXL_ERR_INVALID_BITSTREAM, "squeeze step %d addresses channels outside the list", j);
+        for (int k = begin; k <= end; k++) {
+            const int r = offset + k - begin;
+            const ModChan a = ch[k], re = ch[r];
+            ModOp op{};
+            ModChan o{};
+            if (sp[j].horizontal) {
+                if ((a.w != re.w && a.w != 1 + re.w) || re.h != a.h) return fail(c, JXL_ERR_INVALID_ARGUMENT, "Corrupted squeeze transform");
+                o.w = a.w + re.w; o.h = a.h;
+                op.kind = 0; op.adim = a.w; op.rdim = re.w; op.other = a.h;
+            } else {
+                if ((a.h != re.h && a.h != 1 + re.h) || re.w != a.w) return fail(c, JXL_ERR_STATE, "Corrupted squeeze transform");
+                o.w = a.w; o.h = a.h + re.h;
+                op.kind = 1; op.adim = a.h; op.rdim = re.h; op.other = a.w;
+            }
+            o.d = alloc((size_t)o.w * o.h);
+            if (!o.d) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze output)");
+            o.original = false;
+            op.a = a.d; op.b = re.d; op.o = o.d;
+            c->mod_ops.push_back(op);
+            ch[k] = o;
+        }
+        ch.erase(ch.begin() + offset, ch.begin() + offset + (end - begin + 1));
+    }
+    if (rct_type >= 0) {  // RCT branch (:255-326)
+        if (rct_begin < 0 || rct_begin + 2 >= (int)ch.size()) return fail(c, JXL_ERR_INVALID_ARGUMENT, "rct channels out of range");
+        ModChan* v = &ch[rct_begin];
+        if (v[1].w != v[0].w || v[1].h != v[0].h || v[2].w != v[1].w || v[2].h != v[1].h)
+            return fail(c, JXL_ERR_INVALID_BITSTREAM, "RCT must be performed on three equal size channels");
+        const int64_t n = (int64_t)v[0].w * v[0].h;
+        for (int j = 0; j < 3; j++) {
+            if (v[j].original) {  // keep the uploaded input intact so that run() is repeatable
+                int32_t* d = alloc((size_t)n);
+                if (!d) return fail(c, JXL_ERR_OOM, "device allocation failed (rct copy)");
+                ModOp cp{};
+                cp.kind = 3; cp.a = v[j].d; cp.o = d; cp.n = n;
+                c->mod_ops.push_back(cp);
+                v[j].d = d;
+                v[j].original = false;
+            }
+        }
+        ModOp op{};
+        op.kind = 2; op.v0 = v[0].d; op.v1 = v[1].d; op.v2 = v[2].d; op.n = n; op.type = rct_type % 7;
+        c->mod_ops.push_back(op);
+        const int perm = rct_type / 7;
+        ModChan t[3] = {v[0], v[1], v[2]};
+        for (int j = 0; j < 3; j++) v[kPermutationLut[perm][j]] = t[j];
+    }
+    c->mod_out = ch;
+    return JXL_OK;
+}
+
+jxl_status jxl_modular_run(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    int launches = 0;
+    for (const ModOp& op : c->mod_ops) {
+        switch (op.kind) {
+        case 0: launch_inv_hsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, c->stream); break;
+        case 1: launch_inv_vsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, c->stream); break;
+        case 2: launch_rct(op.v0, op.v1, op.v2, op.n, op.type, c->stream); break;
+        case 3: (void)hipMemcpyAsync(op.o, op.a, 4 * (size_t)op.n, hipMemcpyDeviceToDevice, c->stream); break;
+        }
+        launches++;
+    }
+    c->mod_launches = launches;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+
+int32_t jxl_modular_out_count(const jxl_ctx* c) { return c ? (int32_t)c->mod_out.size() : 0; }
+int32_t jxl_modular_last_launch_count(const jxl_ctx* c) { return c ? c->mod_launches : 0; }
+
+jxl_status jxl_modular_out_shape(const jxl_ctx* c, int32_t idx, int32_t* w, int32_t* h) {
+    if (!c || idx < 0 || idx >= (int)c->mod_out.size() || !w || !h) return JXL_ERR_INVALID_ARGUMENT;
+    *w = c->mod_out[idx].w;
+    *h = c->mod_out[idx].h;
+    return JXL_OK;
+}
+
+jxl_status jxl_modular_read_channel(jxl_ctx* c, int32_t idx, int32_t* dst) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (idx < 0 || idx >= (int)c->mod_out.size() || !dst) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad channel index");
+    if ((st = finish(c))) return st;
+    const size_t n = (size_t)c->mod_out[idx].w * c->mod_out[idx].h;
+    if (n) HIP_TRY(c, hipMemcpy(dst, c->mod_out[idx].d, 4 * n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_modular_apply(jxl_ctx* c, const jxl_channel* chans, int32_t n_chans, const jxl_squeeze_param* sp, int32_t n_sp,
+                             int32_t rct_type, int32_t rct_begin, jxl_channel* out, int32_t n_out) {
+    jxl_status st = jxl_modular_begin(c, chans, n_chans, sp, n_sp, rct_type, rct_begin);
+    if (st) return st;
+    if (n_out != (int)c->mod_out.size() || (n_out > 0 && !out)) return fail(c, JXL_ERR_INVALID_ARGUMENT, "expected %d output channels", (int)c->mod_out.size());
+    for (int i = 0; i < n_out; i++)
+        if (out[i].width != c->mod_out[i].w || out[i].height != c->mod_out[i].h)
+            return fail(c, JXL_ERR_INVALID_ARGUMENT, "output channel %d must be %dx%d", i, c->mod_out[i].w, c->mod_out[i].h);
+    if ((st = jxl_modular_run(c))) return st;
+    for (int i = 0; i < n_out; i++)
+        if ((st = jxl_modular_read_channel(c, i, out[i].data))) return st;
+    return JXL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// Internal declarations shared by the HIP translation units of libjxlatte_amd.so.
+// gfx950 (MI355X) only. All device arithmetic is strict IEEE f32: the library is built with
+// -ffp-contract=off (no FMA contraction), default correctly-rounded f32 division, f32
+// denormals preserved -- required for bit-exact parity with the Java reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/jxlatte_amd.h"
+#include "../../include/jxl_transform_types.h"
+
+namespace jxl {
+
+// total floats of the cosine LUT for sizes 1..256: sum (s-1)*s
+constexpr int kLutTotal = 86870;
+
+// One varblock, frame coordinates. 12 bytes.
+struct DevBlock {
+    uint16_t cy, cx;    // top-left cell (8x8 px units) in the frame
+    uint32_t type;      // TransformType.type
+    uint32_t cfl_zero;  // bit (ty*5+tx): CfL factors of that 64x64 tile (relative to the block's first
+                        // tile) read as 0 for this block -- the reference's per-group xFactors cache has
+                        // not been filled yet when this block is visited (HFCoefficients.java:159-181)
+};
+
+// One workgroup's share of a type-uniform launch.
+struct WorkItem {
+    uint32_t type;
+    uint32_t first;  // index into the binned DevBlock array
+    uint32_t count;  // blocks handled by this workgroup
+};
+
+// Device-resident view of one VarDCT frame (all pointers are device pointers).
+struct DevFrame {
+    int32_t width, height;  // padded px
+    int32_t bw, bh;         // cells
+    int32_t tw, th;         // 64x64 tiles
+    const int32_t* coeff[3];
+    const float* lf[3];     // [bh][bw]
+    const int32_t* hf_mul;  // [bh][bw]
+    const int32_t* sharpness;
+    const int32_t* x_from_y;  // [th][tw]
+    const int32_t* b_from_y;
+    const float* weights;     // flat, reciprocal
+    int32_t woffs[51];
+    const float* lut;         // cosine LUT, all sizes; size s=1<<l starts at lut_off(l)
+    float scale_factor[3];
+    float quant_bias[3];
+    float quant_bias_numerator;
+    float base_corr_x, base_corr_b;
+    float color_factor_f;     // (float)colorFactor
+};
+
+__host__ __device__ inline int lut_off(int l) {
+    // sum_{j<l} (2^j - 1) * 2^j
+    int o = 0;
+    for (int j = 0; j < l; j++) o += ((1 << j) - 1) << j;
+    return o;
+}
+
+struct EpfParams {
+    float channel_scale[3];
+    float sigma_scale;   // stepMultiplier * pass scale for this iteration
+    float border_sad_mul;
+    float inv_sigma_modular;
+};
+
+struct XybParams {
+    float sm[9];         // matrix * itScale
+    float ob[3];         // opsinBias
+    float cob[3];        // -cbrtOpsinBias
+};
+
+// ---- launchers (defined in the kernel TUs) ---------------------------------------------------
+void launch_idct_small(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items,
+                       float* const out[3], hipStream_t s);
+// items of ONE medium type (DCT16..DCT64 and rectangles); count <= medium_blocks_per_wg(type) per item
+void launch_idct_medium_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items_dev, int n_items, int type,
+                             float* const out[3], hipStream_t s);
+int medium_blocks_per_wg(int type);
+// large (128/256-edge) blocks: `first..first+count` of `blocks`; scratch planes same shape as out
+void launch_idct_large(const DevFrame& f, const DevBlock* blocks, const DevBlock* host_blocks, int first, int count,
+                       float* const out[3], float* const scratch[3], hipStream_t s, int* n_launches);
+void launch_accumulate(int32_t* dst, const int32_t* src, int64_t n, hipStream_t s);
+
+void launch_gab(const float* const in[3], float* const out[3], int h, int w, const float w1[3], const float w2[3],
+                hipStream_t s);
+void launch_epf_sigma(const int32_t* hf_mul, const int32_t* sharpness, int bh, int bw, float global_scale_f,
+                      const float sharp_lut[8], float* inv_sigma, int* bad_flag, hipStream_t s);
+void launch_epf_iter(const float* const in[3], float* const out[3], int h, int w, int iter, const float* inv_sigma,
+                     const EpfParams& p, hipStream_t s);
+void launch_xyb(float* const planes[3], int64_t n, const XybParams& p, hipStream_t s);
+void launch_ycbcr(float* const planes[3], int64_t n, hipStream_t s);
+// transfer + quantise: out elem size 4 (float or int32), 2 (u16), 1 (u8)
+void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s);
+// fused restoration + colour tile kernel (Gab -> EPF iters -> XYB -> optional transfer/quantise)
+struct RestoreParams {
+    int gab, epf_iters, xyb, transfer, max_value, out_elem;
+    float gab_base[3], gab_adj[3], gab_diag[3];
+    EpfParams epf[3];  // per iteration index 0..2
+    XybParams xybp;
+    float global_scale_f;
+    float sharp_lut[8];
+};
+// returns false if the configuration is not covered by the fused kernel (caller falls back to stage kernels)
+bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
+                          const int32_t* sharpness, const RestoreParams& p, hipStream_t s);
+
+void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out, hipStream_t s);
+void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh, int w, int32_t* out, hipStream_t s);
+void launch_rct(int32_t* v0, int32_t* v1, int32_t* v2, int64_t n, int type, hipStream_t s);
+void launch_modular_to_float(const int32_t* a, const int32_t* b, int64_t n, float scale, float* out, hipStream_t s);
+
+void launch_idct2d_single(const float* src, float* dst, int h, int w, int transposed, const float* lut, hipStream_t s);
+void launch_fdct2d_single(const float* src, float* dst, int h, int w, const float* lut, hipStream_t s);
+
+}  // namespace jxl

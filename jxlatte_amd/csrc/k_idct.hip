@@ -1,0 +1,814 @@
+// VarDCT stage 1 on gfx950: dequantisation + chroma-from-luma + LLF insertion + inverse
+// transform of every varblock, written straight into the frame planes.
+//
+// Replaces (J/ = java/com/traneptora/jxlatte/):
+//   J/frame/vardct/HFCoefficients.java:140-319  bakeDequantizedCoeffs (dequant, CfL, finalizeLLF)
+//   J/frame/group/PassGroup.java:83-331         invertVarDCT and the special 8x8 transforms
+//   J/util/MathHelper.java:68-145               inverse/forward DCT (direct O(N^2) form, cosine LUT)
+//
+// Bit-exactness rules: every sum keeps the reference's order
+// (dest[k] = src[0]; dest[k] += src[n] * lut[n-1][k], n ascending), multiplies and adds are
+// separate IEEE f32 operations (-ffp-contract=off), no MFMA (fused, different order).
+//
+// Three kernel families, all type-uniform per workgroup so there is no divergence:
+//   small  : the ten 8x8-footprint types. One LANE per varblock, the whole 8x8x3 block lives in
+//            VGPRs, every LUT / AFV-basis factor is an instruction literal: pure VALU, no LDS.
+//   medium : DCT16..DCT64 and their rectangles. One 256-thread workgroup per batch of blocks,
+//            coefficients staged in LDS (row stride W+1: conflict-free), lane = one column for
+//            the column pass and one row for the row pass, accumulators in VGPRs, LUT rows
+//            arrive through scalar loads (wave-uniform).
+//   large  : 128/256-edge blocks do not fit LDS: dequant -> column pass -> row pass through a
+//            scratch plane, 64x64 register tiles per wave.
+#include "jxl_internal.h"
+#include "../../include/jxl_tables.h"
+
+namespace jxl {
+
+#include "lut_small.inc"
+
+static constexpr float kAfv[16][16] = JXL_AFV_BASIS_INIT;
+__constant__ float kLlfScale[32] = JXL_LLF_SCALE_INIT;
+
+template <int N>
+__device__ __forceinline__ constexpr float lutc(int n, int k) {
+    return N == 2 ? kLut2[n][k & 1] : N == 4 ? kLut4[n % 3][k & 3] : kLut8[n % 7][k & 7];
+}
+
+// MathHelper.inverseDCTHorizontal (MathHelper.java:68-78) on register arrays with compile-time strides
+template <int N, int SS, int DS>
+__device__ __forceinline__ void idct1d_reg(const float* s, float* d) {
+    const float s0 = s[0];
+#pragma unroll
+    for (int k = 0; k < N; k++) d[k * DS] = s0;
+#pragma unroll
+    for (int n = 1; n < N; n++) {
+        const float s2 = s[n * SS];
+#pragma unroll
+        for (int k = 0; k < N; k++) d[k * DS] = d[k * DS] + s2 * lutc<N>(n - 1, k);
+    }
+}
+
+// MathHelper.inverseDCT2D (MathHelper.java:96-122). src is H x W (row stride SS).
+// TRANSPOSED=false: dst is H x W; true: dst is W rows x H columns. Row stride of dst = DS.
+template <int H, int W, bool TRANSPOSED, int SS, int DS>
+__device__ __forceinline__ void idct2d_reg(const float* src, float* dst) {
+    float t[H * W];
+    if (TRANSPOSED) {
+#pragma unroll
+        for (int y = 0; y < H; y++) idct1d_reg<W, 1, 1>(src + y * SS, t + y * W);  // rows, length W
+#pragma unroll
+        for (int x = 0; x < W; x++) idct1d_reg<H, W, 1>(t + x, dst + x * DS);      // columns of t -> row x of dst
+    } else {
+#pragma unroll
+        for (int x = 0; x < W; x++) idct1d_reg<H, SS, W>(src + x, t + x);          // columns, length H
+#pragma unroll
+        for (int y = 0; y < H; y++) idct1d_reg<W, 1, 1>(t + y * W, dst + y * DS);  // rows, length W
+    }
+}
+
+// PassGroup.auxDCT2 (PassGroup.java:149-168) on 8x8 register blocks
+template <int S>
+__device__ __forceinline__ void aux_dct2_reg(const float* in, float* out) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) out[i] = in[i];
+    constexpr int num = S / 2;
+#pragma unroll
+    for (int iy = 0; iy < num; iy++) {
+#pragma unroll
+        for (int ix = 0; ix < num; ix++) {
+            const float c00 = in[iy * 8 + ix];
+            const float c01 = in[iy * 8 + ix + num];
+            const float c10 = in[(iy + num) * 8 + ix];
+            const float c11 = in[(iy + num) * 8 + ix + num];
+            out[(iy * 2) * 8 + ix * 2] = c00 + c01 + c10 + c11;
+            out[(iy * 2) * 8 + ix * 2 + 1] = c00 + c01 - c10 - c11;
+            out[(iy * 2 + 1) * 8 + ix * 2] = c00 - c01 + c10 - c11;
+            out[(iy * 2 + 1) * 8 + ix * 2 + 1] = c00 - c01 - c10 + c11;
+        }
+    }
+}
+
+// the per-type switch of PassGroup.invertVarDCT (PassGroup.java:229-328) for the 8x8-footprint
+// types; co = dequantised coefficients (8x8, stride 8), px = pixels (8x8, stride 8)
+template <int TYPE>
+__device__ __forceinline__ void invert_small(const float* co, float* px) {
+    if (TYPE == 0) {  // DCT8
+        idct2d_reg<8, 8, false, 8, 8>(co, px);
+    } else if (TYPE == 13) {  // DCT8_4 (:234-251)
+        const float coeff0 = co[0], coeff1 = co[8];
+        const float lfs[2] = {coeff0 + coeff1, coeff0 - coeff1};
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            float s[32];
+#pragma unroll
+            for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+                for (int ix = 0; ix < 8; ix++) s[iy * 8 + ix] = co[(x + iy * 2) * 8 + ix];
+            s[0] = lfs[x];
+            idct2d_reg<4, 8, true, 8, 8>(s, px + (x << 2));
+        }
+    } else if (TYPE == 12) {  // DCT4_8 (:252-269)
+        const float coeff0 = co[0], coeff1 = co[8];
+        const float lfs[2] = {coeff0 + coeff1, coeff0 - coeff1};
+#pragma unroll
+        for (int y = 0; y < 2; y++) {
+            float s[32];
+#pragma unroll
+            for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+                for (int ix = 0; ix < 8; ix++) s[iy * 8 + ix] = co[(y + iy * 2) * 8 + ix];
+            s[0] = lfs[y];
+            idct2d_reg<4, 8, false, 8, 8>(s, px + (y << 2) * 8);
+        }
+    } else if (TYPE >= 14 && TYPE <= 17) {  // AFV0..3: PassGroup.invertAFV (:88-147)
+        constexpr int flipY = (TYPE == 16 || TYPE == 17) ? 1 : 0;
+        constexpr int flipX = (TYPE == 15 || TYPE == 17) ? 1 : 0;
+        float s0[16], s1[16];
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 4; ix++) s0[iy * 4 + ix] = co[(iy * 2) * 8 + ix * 2];
+        s0[0] = (co[0] + co[8] + co[1]) * 4.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            float sample = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) sample = sample + s0[j] * kAfv[j][i];
+            s1[i] = sample;
+        }
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 4; ix++)
+                px[(flipY * 4 + iy) * 8 + flipX * 4 + ix] = s1[(flipY ? 3 - iy : iy) * 4 + (flipX ? 3 - ix : ix)];
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 4; ix++) s0[iy * 4 + ix] = co[(iy * 2) * 8 + ix * 2 + 1];
+        s0[0] = co[0] + co[8] - co[1];
+        idct2d_reg<4, 4, false, 4, 4>(s0, s1);
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 4; ix++)  // transposed intentionally (:129-131)
+                px[(flipY * 4 + iy) * 8 + (flipX ? 0 : 4) + ix] = s1[ix * 4 + iy];
+        float r0[32], r1[32];
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 8; ix++) r0[iy * 8 + ix] = co[(1 + iy * 2) * 8 + ix];
+        r0[0] = co[0] - co[8];
+        idct2d_reg<4, 8, false, 8, 8>(r0, r1);
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+            for (int ix = 0; ix < 8; ix++) px[((flipY ? 0 : 4) + iy) * 8 + ix] = r1[iy * 8 + ix];
+    } else if (TYPE == 2) {  // DCT2 (:273-277)
+        float a[64], b[64];
+        aux_dct2_reg<2>(co, a);
+        aux_dct2_reg<4>(a, b);
+        aux_dct2_reg<8>(b, px);
+    } else if (TYPE == 1) {  // HORNUSS (:278-305)
+        // auxDCT2(coeffs, s1, 2): only s1[y][x], y,x < 2 are consumed
+        const float c00 = co[0], c01 = co[1], c10 = co[8], c11 = co[9];
+        const float lf4[4] = {c00 + c01 + c10 + c11, c00 + c01 - c10 - c11, c00 - c01 + c10 - c11, c00 - c01 - c10 + c11};
+#pragma unroll
+        for (int y = 0; y < 2; y++) {
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                const float blockLF = lf4[y * 2 + x];
+                float residual = 0.0f;
+#pragma unroll
+                for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+                    for (int ix = (iy == 0 ? 1 : 0); ix < 4; ix++) residual = residual + co[(y + iy * 2) * 8 + x + ix * 2];
+                const float a = blockLF - residual * 0.0625f;
+                px[(4 * y + 1) * 8 + 4 * x + 1] = a;
+#pragma unroll
+                for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+                    for (int ix = 0; ix < 4; ix++) {
+                        if (ix == 1 && iy == 1) continue;
+                        px[(y * 4 + iy) * 8 + x * 4 + ix] = co[(y + iy * 2) * 8 + x + ix * 2] + a;
+                    }
+                px[(4 * y) * 8 + 4 * x] = co[(y + 2) * 8 + x + 2] + a;
+            }
+        }
+    } else if (TYPE == 3) {  // DCT4 (:306-325)
+        const float c00 = co[0], c01 = co[1], c10 = co[8], c11 = co[9];
+        const float lf4[4] = {c00 + c01 + c10 + c11, c00 + c01 - c10 - c11, c00 - c01 + c10 - c11, c00 - c01 - c10 + c11};
+#pragma unroll
+        for (int y = 0; y < 2; y++) {
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                float s[16], t[16];
+#pragma unroll
+                for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+                    for (int ix = 0; ix < 4; ix++) s[iy * 4 + ix] = co[(y + iy * 2) * 8 + x + ix * 2];
+                s[0] = lf4[y * 2 + x];
+                idct2d_reg<4, 4, true, 4, 4>(s, t);
+#pragma unroll
+                for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+                    for (int ix = 0; ix < 4; ix++) px[(4 * y + iy) * 8 + 4 * x + ix] = t[iy * 4 + ix];
+            }
+        }
+    }
+}
+
+// HFCoefficients.dequantizeHFCoefficients inner expression (HFCoefficients.java:309-315)
+__device__ __forceinline__ float dequant1(int32_t q, float qb, float qbn, float sfc, float w) {
+    const float quant = (q > -2 && q < 2) ? (q == 0 ? 0.0f : (q > 0 ? qb : -qb)) : (float)q - qbn / (float)q;
+    return quant * sfc * w;
+}
+
+// CfL factors of one tile for one block (HFCoefficients.java:177-181) honouring the reference's
+// per-group cache order (DevBlock::cfl_zero)
+__device__ __forceinline__ void cfl_factors(const DevFrame& f, int ty, int tx, bool zero, float& kX, float& kB) {
+    if (zero) {
+        kX = 0.0f;
+        kB = 0.0f;
+    } else {
+        kX = f.base_corr_x + (float)f.x_from_y[ty * f.tw + tx] / f.color_factor_f;
+        kB = f.base_corr_b + (float)f.b_from_y[ty * f.tw + tx] / f.color_factor_f;
+    }
+}
+
+// ---- small: one lane = one 8x8 varblock, 3 channels -----------------------------------------------
+template <int TYPE>
+__device__ __forceinline__ void small_block(const DevFrame& f, const DevBlock b, float* __restrict__ o0,
+                                            float* __restrict__ o1, float* __restrict__ o2) {
+    constexpr int PI = TYPE == 0 ? 0 : TYPE == 1 ? 1 : TYPE == 2 ? 2 : TYPE == 3 ? 3 : (TYPE == 12 || TYPE == 13) ? 9 : 10;
+    constexpr bool FLIP = TYPE == 0;  // TransformType.flip(): square METHOD_DCT
+    const int W = f.width;
+    const int py0 = b.cy * 8, px0 = b.cx * 8;
+    const int64_t base = (int64_t)py0 * W + px0;
+    const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+    float kX, kB;
+    cfl_factors(f, py0 >> 6, px0 >> 6, b.cfl_zero & 1u, kX, kB);
+    float* outs[3] = {o0, o1, o2};
+
+    float dqY[64];
+    {
+        const float* w = f.weights + f.woffs[PI * 3 + 1];
+        const float sfc = f.scale_factor[1] / hfm;
+        const float qb = f.quant_bias[1];
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            const int4 a = *reinterpret_cast<const int4*>(f.coeff[1] + base + (int64_t)y * W);
+            const int4 c = *reinterpret_cast<const int4*>(f.coeff[1] + base + (int64_t)y * W + 4);
+            const int q[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+                dqY[y * 8 + x] = dequant1(q[x], qb, f.quant_bias_numerator, sfc, w[FLIP ? x * 8 + y : y * 8 + x]);
+        }
+        dqY[0] = 0.0f;  // LLF corner is skipped by the dequantiser (:305-306); CfL reads 0 there
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 0 : ci == 1 ? 2 : 1;  // X, B, then Y
+        float co[64];
+        if (c == 1) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) co[i] = dqY[i];
+        } else {
+            const float* w = f.weights + f.woffs[PI * 3 + c];
+            const float sfc = f.scale_factor[c] / hfm;
+            const float qb = f.quant_bias[c];
+            const float k = c == 0 ? kX : kB;
+#pragma unroll
+            for (int y = 0; y < 8; y++) {
+                const int4 a = *reinterpret_cast<const int4*>(f.coeff[c] + base + (int64_t)y * W);
+                const int4 d = *reinterpret_cast<const int4*>(f.coeff[c] + base + (int64_t)y * W + 4);
+                const int q[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    const float v = dequant1(q[x], qb, f.quant_bias_numerator, sfc, w[FLIP ? x * 8 + y : y * 8 + x]);
+                    co[y * 8 + x] = v + k * dqY[y * 8 + x];  // chromaFromLuma (:186-188)
+                }
+            }
+        }
+        // finalizeLLF for a 1x1 dctSelect: forwardDCT2D of one sample is sample * (1f/1) twice, llfScale = 1f*1f:
+        // multiplications by exactly 1.0f, i.e. the LF sample itself
+        co[0] = f.lf[c][b.cy * f.bw + b.cx];
+        float px[64];
+        invert_small<TYPE>(co, px);
+        float* o = outs[c] + base;
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            *reinterpret_cast<float4*>(o + (int64_t)y * W) = make_float4(px[y * 8], px[y * 8 + 1], px[y * 8 + 2], px[y * 8 + 3]);
+            *reinterpret_cast<float4*>(o + (int64_t)y * W + 4) =
+                make_float4(px[y * 8 + 4], px[y * 8 + 5], px[y * 8 + 6], px[y * 8 + 7]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_idct_small(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                   const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    const WorkItem it = items[blockIdx.x];
+    if (threadIdx.x >= it.count) return;
+    const DevBlock b = blocks[it.first + threadIdx.x];
+    switch (it.type) {
+    case 0: small_block<0>(f, b, o0, o1, o2); break;
+    case 1: small_block<1>(f, b, o0, o1, o2); break;
+    case 2: small_block<2>(f, b, o0, o1, o2); break;
+    case 3: small_block<3>(f, b, o0, o1, o2); break;
+    case 12: small_block<12>(f, b, o0, o1, o2); break;
+    case 13: small_block<13>(f, b, o0, o1, o2); break;
+    case 14: small_block<14>(f, b, o0, o1, o2); break;
+    case 15: small_block<15>(f, b, o0, o1, o2); break;
+    case 16: small_block<16>(f, b, o0, o1, o2); break;
+    case 17: small_block<17>(f, b, o0, o1, o2); break;
+    default: break;
+    }
+}
+
+void launch_idct_small(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items,
+                       float* const out[3], hipStream_t s) {
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(k_idct_small, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
+}
+
+// ---- shared pieces of medium / large ---------------------------------------------------------------
+__device__ __forceinline__ int ceil_log2_dev(int x) {
+    int l = 0;
+    while ((1 << l) < x) l++;
+    return l;
+}
+
+// dequant + CfL of one sample position of a block (all three channels).
+// (y, x) are relative to the block; returns dq[3]. LLF corner samples return 0 (filled later).
+struct BlockCtx {
+    int py0, px0, H, W;       // footprint
+    int dsh, dsw;             // dctSelect size
+    int ty0, tx0;             // first tile
+    uint32_t cfl_zero;
+    float sfc[3];
+    const float* w[3];
+    int mw;                   // weight matrix row stride (matrixWidth)
+    bool flip;
+};
+
+__device__ __forceinline__ void make_block_ctx(const DevFrame& f, const DevBlock b, int H, int W, int PI, BlockCtx& k) {
+    k.py0 = b.cy * 8;
+    k.px0 = b.cx * 8;
+    k.H = H;
+    k.W = W;
+    k.dsh = H >> 3;
+    k.dsw = W >> 3;
+    k.ty0 = k.py0 >> 6;
+    k.tx0 = k.px0 >> 6;
+    k.cfl_zero = b.cfl_zero;
+    const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+    for (int c = 0; c < 3; c++) {
+        k.sfc[c] = f.scale_factor[c] / hfm;
+        k.w[c] = f.weights + f.woffs[PI * 3 + c];
+    }
+    k.mw = H < W ? W : H;
+    k.flip = H >= W;  // METHOD_DCT: tall or square
+}
+
+__device__ __forceinline__ void dequant_sample(const DevFrame& f, const BlockCtx& k, int y, int x, float dq[3]) {
+    if (y < k.dsh && x < k.dsw) {
+        dq[0] = dq[1] = dq[2] = 0.0f;
+        return;
+    }
+    const int64_t off = (int64_t)(k.py0 + y) * f.width + k.px0 + x;
+    const int wy = k.flip ? x : y, wx = k.flip ? y : x;
+    const int wi = wy * k.mw + wx;
+    const float dy = dequant1(f.coeff[1][off], f.quant_bias[1], f.quant_bias_numerator, k.sfc[1], k.w[1][wi]);
+    const float dx = dequant1(f.coeff[0][off], f.quant_bias[0], f.quant_bias_numerator, k.sfc[0], k.w[0][wi]);
+    const float db = dequant1(f.coeff[2][off], f.quant_bias[2], f.quant_bias_numerator, k.sfc[2], k.w[2][wi]);
+    const int ty = (k.py0 + y) >> 6, tx = (k.px0 + x) >> 6;
+    const int bit = (ty - k.ty0) * 5 + (tx - k.tx0);
+    float kX, kB;
+    cfl_factors(f, ty, tx, (k.cfl_zero >> bit) & 1u, kX, kB);
+    dq[0] = dx + kX * dy;
+    dq[1] = dy;
+    dq[2] = db + kB * dy;
+}
+
+// finalizeLLF (HFCoefficients.java:194-229) for one block and channel, executed by `nthr` threads
+// (thread ids tid = 0..nthr-1) of a workgroup. s0/s1: LDS scratch of dsh*dsw floats each. Writes
+// the dsh x dsw corner through put(k_row, k_col, value). Contains __syncthreads: call uniformly.
+template <typename Put>
+__device__ __forceinline__ void llf_block(const DevFrame& f, int cy, int cx, int c, int dsh, int dsw, float* s0, float* s1,
+                                          int tid, int nthr, Put put) {
+    const int lw = ceil_log2_dev(dsw), lh = ceil_log2_dev(dsh);
+    const float* lutw = f.lut + lut_off(lw);
+    const float* luth = f.lut + lut_off(lh);
+    const float* src = f.lf[c] + (int64_t)cy * f.bw + cx;
+    // rows: forwardDCTHorizontal of length dsw on each of the dsh rows -> s0[y][k]
+    for (int i = tid; i < dsh * dsw; i += nthr) {
+        const int y = i / dsw, k = i % dsw;
+        const float inv = 1.0f / (float)dsw;
+        const float* r = src + (int64_t)y * f.bw;
+        float d2;
+        if (k == 0) {
+            d2 = r[0];
+            for (int x = 1; x < dsw; ++x) d2 = d2 + r[x];
+        } else {
+            const float* lut = lutw + (k - 1) * dsw;
+            d2 = r[0] * lut[0];
+            for (int n = 1; n < dsw; ++n) d2 = d2 + r[n] * lut[n];
+        }
+        s0[y * dsw + k] = d2 * inv;
+    }
+    __syncthreads();
+    // transpose (s1[x][y] = s0[y][x]) folded into indexing; columns: length dsh on each of the dsw rows of s1
+    for (int i = tid; i < dsh * dsw; i += nthr) {
+        const int x = i / dsh, k = i % dsh;
+        const float inv = 1.0f / (float)dsh;
+        float d2;
+        if (k == 0) {
+            d2 = s0[0 * dsw + x];
+            for (int y = 1; y < dsh; ++y) d2 = d2 + s0[y * dsw + x];
+        } else {
+            const float* lut = luth + (k - 1) * dsh;
+            d2 = s0[0 * dsw + x] * lut[0];
+            for (int n = 1; n < dsh; ++n) d2 = d2 + s0[n * dsw + x] * lut[n];
+        }
+        s1[x * dsh + k] = d2 * inv;
+    }
+    __syncthreads();
+    // transposeMatrixInto(scratch0, dest, ...): dest[k][x] = s1[x][k]; then *= llfScale[k][x]
+    const int yll = ceil_log2_dev(dsh), xll = ceil_log2_dev(dsw);
+    for (int i = tid; i < dsh * dsw; i += nthr) {
+        const int k = i / dsw, x = i % dsw;
+        const float sc = kLlfScale[k << (5 - yll)] * kLlfScale[x << (5 - xll)];
+        put(k, x, s1[x * dsh + k] * sc);
+    }
+    __syncthreads();
+}
+
+// ---- medium: DCT16..DCT64 and rectangles, LDS resident ----------------------------------------------
+template <int H, int W>
+struct MediumCfg {
+    static constexpr int MAXD = H > W ? H : W;
+    static constexpr int NB = (256 / (3 * MAXD)) > 0 ? (256 / (3 * MAXD)) : 1;  // blocks per workgroup
+    static constexpr int LD = W + 1;                                           // padded row stride
+    static constexpr int BLK_FLOATS = 3 * H * LD;
+    static constexpr int LLF_FLOATS = 2 * (H / 8) * (W / 8);                   // per (block, channel) scratch pair
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(NB * BLK_FLOATS + 2 * 64);
+};
+
+template <int H, int W, int TYPE>
+__global__ __launch_bounds__(256) void k_idct_medium(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                     const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    using Cfg = MediumCfg<H, W>;
+    constexpr int NB = Cfg::NB, LD = Cfg::LD;
+    constexpr int PI = JXL_TT[TYPE].param_index;
+    extern __shared__ float lds[];
+    float* buf = lds;                           // [NB][3][H][LD]
+    float* llf_s = lds + NB * Cfg::BLK_FLOATS;  // 2 x 64 floats
+    const WorkItem it = items[blockIdx.x];
+    const int nb = (int)it.count;
+    const int tid = threadIdx.x;
+    const int FW = f.width;
+    float* outs[3] = {o0, o1, o2};
+
+    // 1. dequant + CfL -> LDS
+    for (int bi = 0; bi < nb; bi++) {
+        const DevBlock b = blocks[it.first + bi];
+        BlockCtx k;
+        make_block_ctx(f, b, H, W, PI, k);
+        float* bb = buf + bi * Cfg::BLK_FLOATS;
+        for (int i = tid; i < H * W; i += 256) {
+            const int y = i / W, x = i % W;
+            float dq[3];
+            dequant_sample(f, k, y, x, dq);
+            bb[(0 * H + y) * LD + x] = dq[0];
+            bb[(1 * H + y) * LD + x] = dq[1];
+            bb[(2 * H + y) * LD + x] = dq[2];
+        }
+    }
+    __syncthreads();
+    // 2. LLF corner
+    for (int bi = 0; bi < nb; bi++) {
+        const DevBlock b = blocks[it.first + bi];
+        float* bb = buf + bi * Cfg::BLK_FLOATS;
+        for (int c = 0; c < 3; c++) {
+            llf_block(f, b.cy, b.cx, c, H / 8, W / 8, llf_s, llf_s + 64, tid, 256,
+                      [&](int ky, int kx, float v) { bb[(c * H + ky) * LD + kx] = v; });
+        }
+    }
+    __syncthreads();
+    // 3. column pass: lane = (block, channel, column); H accumulators in VGPRs
+    {
+        const float* lut = f.lut + lut_off(ceil_log2_dev(H));
+        if (tid < nb * 3 * W) {
+            const int bi = tid / (3 * W), r = tid % (3 * W), c = r / W, x = r % W;
+            float* col = buf + bi * Cfg::BLK_FLOATS + (c * H) * LD + x;
+            float acc[H];
+            const float s0 = col[0];
+#pragma unroll
+            for (int k2 = 0; k2 < H; k2++) acc[k2] = s0;
+            for (int n = 1; n < H; n++) {
+                const float s2 = col[n * LD];
+                const float* lr = lut + (n - 1) * H;
+#pragma unroll
+                for (int k2 = 0; k2 < H; k2++) acc[k2] = acc[k2] + s2 * lr[k2];
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < H; k2++) col[k2 * LD] = acc[k2];
+        }
+    }
+    __syncthreads();
+    // 4. row pass: lane = (block, channel, row); W accumulators
+    {
+        const float* lut = f.lut + lut_off(ceil_log2_dev(W));
+        if (tid < nb * 3 * H) {
+            const int bi = tid / (3 * H), r = tid % (3 * H), c = r / H, y = r % H;
+            float* row = buf + bi * Cfg::BLK_FLOATS + (c * H + y) * LD;
+            float acc[W];
+            const float s0 = row[0];
+#pragma unroll
+            for (int k2 = 0; k2 < W; k2++) acc[k2] = s0;
+            for (int n = 1; n < W; n++) {
+                const float s2 = row[n];
+                const float* lr = lut + (n - 1) * W;
+#pragma unroll
+                for (int k2 = 0; k2 < W; k2++) acc[k2] = acc[k2] + s2 * lr[k2];
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < W; k2++) row[k2] = acc[k2];
+        }
+    }
+    __syncthreads();
+    // 5. coalesced store
+    for (int bi = 0; bi < nb; bi++) {
+        const DevBlock b = blocks[it.first + bi];
+        const float* bb = buf + bi * Cfg::BLK_FLOATS;
+        const int64_t base = (int64_t)(b.cy * 8) * FW + b.cx * 8;
+        for (int i = tid; i < 3 * H * W; i += 256) {
+            const int c = i / (H * W), r = i % (H * W), y = r / W, x = r % W;
+            outs[c][base + (int64_t)y * FW + x] = bb[(c * H + y) * LD + x];
+        }
+    }
+}
+
+template <int H, int W, int TYPE>
+static void launch_medium_t(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n, float* const out[3],
+                            hipStream_t s) {
+    using Cfg = MediumCfg<H, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_medium<H, W, TYPE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_idct_medium<H, W, TYPE>), dim3(n), dim3(256), Cfg::LDS_BYTES, s, f, blocks, items, out[0], out[1],
+                       out[2]);
+}
+
+int medium_blocks_per_wg(int type) {
+    const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
+    const int m = h > w ? h : w;
+    const int nb = 256 / (3 * m);
+    return nb > 0 ? nb : 1;
+}
+
+void launch_idct_medium_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items_dev, int n_items, int type,
+                             float* const out[3], hipStream_t s) {
+    if (n_items <= 0) return;
+    switch (type) {
+    case 4: launch_medium_t<16, 16, 4>(f, blocks, items_dev, n_items, out, s); break;
+    case 5: launch_medium_t<32, 32, 5>(f, blocks, items_dev, n_items, out, s); break;
+    case 6: launch_medium_t<16, 8, 6>(f, blocks, items_dev, n_items, out, s); break;
+    case 7: launch_medium_t<8, 16, 7>(f, blocks, items_dev, n_items, out, s); break;
+    case 8: launch_medium_t<32, 8, 8>(f, blocks, items_dev, n_items, out, s); break;
+    case 9: launch_medium_t<8, 32, 9>(f, blocks, items_dev, n_items, out, s); break;
+    case 10: launch_medium_t<32, 16, 10>(f, blocks, items_dev, n_items, out, s); break;
+    case 11: launch_medium_t<16, 32, 11>(f, blocks, items_dev, n_items, out, s); break;
+    case 18: launch_medium_t<64, 64, 18>(f, blocks, items_dev, n_items, out, s); break;
+    case 19: launch_medium_t<64, 32, 19>(f, blocks, items_dev, n_items, out, s); break;
+    case 20: launch_medium_t<32, 64, 20>(f, blocks, items_dev, n_items, out, s); break;
+    default: break;
+    }
+}
+
+// ---- large: 128/256-edge blocks through a scratch plane ---------------------------------------------
+// phase A: dequant + CfL of every sample -> out planes (used as the coefficient store); grid.y = block
+__global__ __launch_bounds__(256) void k_large_dequant(const DevFrame f, const DevBlock* __restrict__ blocks, int first,
+                                                       float* o0, float* o1, float* o2) {
+    const DevBlock b = blocks[first + blockIdx.y];
+    const jxl_tt_info tt = JXL_TT[b.type];
+    BlockCtx k;
+    make_block_ctx(f, b, tt.ph, tt.pw, tt.param_index, k);
+    const int n = tt.ph * tt.pw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int y = i / tt.pw, x = i % tt.pw;
+        float dq[3];
+        dequant_sample(f, k, y, x, dq);
+        const int64_t off = (int64_t)(k.py0 + y) * f.width + k.px0 + x;
+        o0[off] = dq[0];
+        o1[off] = dq[1];
+        o2[off] = dq[2];
+    }
+}
+
+// phase A2: LLF corner (up to 32x32) per (block, channel): grid = (3, nblocks)
+__global__ __launch_bounds__(256) void k_large_llf(const DevFrame f, const DevBlock* __restrict__ blocks, int first, float* o0,
+                                                   float* o1, float* o2) {
+    __shared__ float s0[1024], s1[1024];
+    const DevBlock b = blocks[first + blockIdx.y];
+    const jxl_tt_info tt = JXL_TT[b.type];
+    const int c = blockIdx.x;
+    float* o = c == 0 ? o0 : c == 1 ? o1 : o2;
+    const int64_t base = (int64_t)(b.cy * 8) * f.width + b.cx * 8;
+    const int FW = f.width;
+    llf_block(f, b.cy, b.cx, c, tt.ph >> 3, tt.pw >> 3, s0, s1, threadIdx.x, 256,
+              [&](int ky, int kx, float v) { o[base + (int64_t)ky * FW + kx] = v; });
+}
+
+// phase B: column pass. unit = (block, channel, 64-column strip, 64-output chunk); one wave per unit.
+// src/dst are frame planes; lane = column. dst[k][x] = idct over n of src[n][x].
+__global__ __launch_bounds__(64) void k_large_colpass(const DevFrame f, const DevBlock* __restrict__ blocks, int first,
+                                                      const float* s0p, const float* s1p, const float* s2p, float* d0, float* d1,
+                                                      float* d2) {
+    const DevBlock b = blocks[first + blockIdx.z];
+    const jxl_tt_info tt = JXL_TT[b.type];
+    const int H = tt.ph, W = tt.pw;
+    const int c = blockIdx.y;
+    const int strips = W / 64, chunks = H / 64;
+    const int u = blockIdx.x;
+    if (u >= strips * chunks) return;
+    const int strip = u % strips, chunk = u / strips;
+    const float* src = c == 0 ? s0p : c == 1 ? s1p : s2p;
+    float* dst = c == 0 ? d0 : c == 1 ? d1 : d2;
+    const int FW = f.width;
+    const int64_t base = (int64_t)(b.cy * 8) * FW + b.cx * 8 + strip * 64 + threadIdx.x;
+    const float* lut = f.lut + lut_off(ceil_log2_dev(H)) + chunk * 64;
+    float acc[64];
+    const float s0 = src[base];
+#pragma unroll
+    for (int k = 0; k < 64; k++) acc[k] = s0;
+    for (int n = 1; n < H; n++) {
+        const float s2 = src[base + (int64_t)n * FW];
+        const float* lr = lut + (n - 1) * H;
+#pragma unroll
+        for (int k = 0; k < 64; k++) acc[k] = acc[k] + s2 * lr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 64; k++) dst[base + (int64_t)(chunk * 64 + k) * FW] = acc[k];
+}
+
+// phase C: row pass. unit = (block, channel, 64-row strip, 64-output chunk); lane = row, tiles staged
+// through LDS so that global loads and stores stay row-contiguous.
+__global__ __launch_bounds__(64) void k_large_rowpass(const DevFrame f, const DevBlock* __restrict__ blocks, int first,
+                                                      const float* s0p, const float* s1p, const float* s2p, float* d0, float* d1,
+                                                      float* d2) {
+    __shared__ float tile[64 * 65];
+    const DevBlock b = blocks[first + blockIdx.z];
+    const jxl_tt_info tt = JXL_TT[b.type];
+    const int H = tt.ph, W = tt.pw;
+    const int c = blockIdx.y;
+    const int strips = H / 64, chunks = W / 64;
+    const int u = blockIdx.x;
+    if (u >= strips * chunks) return;
+    const int strip = u % strips, chunk = u / strips;
+    const float* src = c == 0 ? s0p : c == 1 ? s1p : s2p;
+    float* dst = c == 0 ? d0 : c == 1 ? d1 : d2;
+    const int FW = f.width;
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)(b.cy * 8 + strip * 64) * FW + b.cx * 8;
+    const float* lut = f.lut + lut_off(ceil_log2_dev(W)) + chunk * 64;
+    float acc[64];
+    for (int n0 = 0; n0 < W; n0 += 64) {
+        __syncthreads();
+        for (int r = 0; r < 64; r++) tile[r * 65 + lane] = src[base + (int64_t)r * FW + n0 + lane];
+        __syncthreads();
+        for (int nn = 0; nn < 64; nn++) {
+            const int n = n0 + nn;
+            const float s2 = tile[lane * 65 + nn];
+            if (n == 0) {
+#pragma unroll
+                for (int k = 0; k < 64; k++) acc[k] = s2;
+            } else {
+                const float* lr = lut + (n - 1) * W;
+#pragma unroll
+                for (int k = 0; k < 64; k++) acc[k] = acc[k] + s2 * lr[k];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 64; k++) tile[lane * 65 + k] = acc[k];
+    __syncthreads();
+    for (int r = 0; r < 64; r++) dst[base + (int64_t)r * FW + chunk * 64 + lane] = tile[r * 65 + lane];
+}
+
+void launch_idct_large(const DevFrame& f, const DevBlock* blocks, const DevBlock* host_blocks, int first, int count,
+                       float* const out[3], float* const scratch[3], hipStream_t s, int* n_launches) {
+    (void)host_blocks;
+    if (count <= 0) return;
+    // every large type has <= 256x256 samples: 32 workgroups of 256 threads x 8 samples
+    hipLaunchKernelGGL(k_large_dequant, dim3(32, count), dim3(256), 0, s, f, blocks, first, out[0], out[1], out[2]);
+    hipLaunchKernelGGL(k_large_llf, dim3(3, count), dim3(256), 0, s, f, blocks, first, out[0], out[1], out[2]);
+    // at most (256/64)*(256/64) = 16 units per (block, channel)
+    hipLaunchKernelGGL(k_large_colpass, dim3(16, 3, count), dim3(64), 0, s, f, blocks, first, out[0], out[1], out[2],
+                       scratch[0], scratch[1], scratch[2]);
+    hipLaunchKernelGGL(k_large_rowpass, dim3(16, 3, count), dim3(64), 0, s, f, blocks, first, scratch[0], scratch[1],
+                       scratch[2], out[0], out[1], out[2]);
+    if (n_launches) *n_launches += 4;
+}
+
+__global__ void k_accumulate(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (int32_t)((uint32_t)dst[i] + (uint32_t)src[i]);  // PassGroup.java:174-200, Java int wrap
+}
+
+void launch_accumulate(int32_t* dst, const int32_t* src, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, dst, src, n);
+}
+
+// ---- single-block 2-D transforms for the stage-level entry points ------------------------------------
+// One workgroup, everything in global memory, one thread per 1-D transform: slow, exact, any size.
+__global__ __launch_bounds__(256) void k_idct2d_single(const float* src, float* dst, float* tmp, int h, int w, int transposed,
+                                                       const float* lut_all) {
+    const int lh = ceil_log2_dev(h), lw = ceil_log2_dev(w);
+    const float* luth = lut_all + lut_off(lh);
+    const float* lutw = lut_all + lut_off(lw);
+    if (transposed) {
+        for (int y = threadIdx.x; y < h; y += 256)
+            for (int k = 0; k < w; k++) {
+                float d = src[y * w];
+                for (int n = 1; n < w; n++) d = d + src[y * w + n] * lutw[(n - 1) * w + k];
+                tmp[y * w + k] = d;
+            }
+        __syncthreads();
+        for (int x = threadIdx.x; x < w; x += 256)
+            for (int k = 0; k < h; k++) {
+                float d = tmp[x];
+                for (int n = 1; n < h; n++) d = d + tmp[n * w + x] * luth[(n - 1) * h + k];
+                dst[x * h + k] = d;
+            }
+    } else {
+        for (int x = threadIdx.x; x < w; x += 256)
+            for (int k = 0; k < h; k++) {
+                float d = src[x];
+                for (int n = 1; n < h; n++) d = d + src[n * w + x] * luth[(n - 1) * h + k];
+                tmp[k * w + x] = d;
+            }
+        __syncthreads();
+        for (int y = threadIdx.x; y < h; y += 256)
+            for (int k = 0; k < w; k++) {
+                float d = tmp[y * w];
+                for (int n = 1; n < w; n++) d = d + tmp[y * w + n] * lutw[(n - 1) * w + k];
+                dst[y * w + k] = d;
+            }
+    }
+}
+
+// MathHelper.forwardDCT2D (MathHelper.java:124-136)
+__global__ __launch_bounds__(256) void k_fdct2d_single(const float* src, float* dst, float* tmp, int h, int w,
+                                                       const float* lut_all) {
+    const int lh = ceil_log2_dev(h), lw = ceil_log2_dev(w);
+    const float* luth = lut_all + lut_off(lh);
+    const float* lutw = lut_all + lut_off(lw);
+    for (int i = threadIdx.x; i < h * w; i += 256) {
+        const int y = i / w, k = i % w;
+        const float inv = 1.0f / (float)w;
+        float d2;
+        if (k == 0) {
+            d2 = src[y * w];
+            for (int x = 1; x < w; x++) d2 = d2 + src[y * w + x];
+        } else {
+            d2 = src[y * w] * lutw[(k - 1) * w];
+            for (int n = 1; n < w; n++) d2 = d2 + src[y * w + n] * lutw[(k - 1) * w + n];
+        }
+        tmp[y * w + k] = d2 * inv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < h * w; i += 256) {
+        const int x = i / h, k = i % h;
+        const float inv = 1.0f / (float)h;
+        float d2;
+        if (k == 0) {
+            d2 = tmp[x];
+            for (int y = 1; y < h; y++) d2 = d2 + tmp[y * w + x];
+        } else {
+            d2 = tmp[x] * luth[(k - 1) * h];
+            for (int n = 1; n < h; n++) d2 = d2 + tmp[n * w + x] * luth[(k - 1) * h + n];
+        }
+        dst[k * w + x] = d2 * inv;
+    }
+}
+
+static float* g_single_tmp = nullptr;
+
+void launch_idct2d_single(const float* src, float* dst, int h, int w, int transposed, const float* lut, hipStream_t s) {
+    if (!g_single_tmp) (void)hipMalloc(&g_single_tmp, sizeof(float) * 256 * 256);
+    hipLaunchKernelGGL(k_idct2d_single, dim3(1), dim3(256), 0, s, src, dst, g_single_tmp, h, w, transposed, lut);
+}
+
+void launch_fdct2d_single(const float* src, float* dst, int h, int w, const float* lut, hipStream_t s) {
+    if (!g_single_tmp) (void)hipMalloc(&g_single_tmp, sizeof(float) * 256 * 256);
+    hipLaunchKernelGGL(k_fdct2d_single, dim3(1), dim3(256), 0, s, src, dst, g_single_tmp, h, w, lut);
+}
+
+}  // namespace jxl

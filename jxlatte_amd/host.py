@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's interface for the transform stage, on top of the C-ABI.
+
+Names, argument meaning and error behaviour follow the Java classes the path lives in
+(J/ = java/com/traneptora/jxlatte/): `MathHelper.inverseDCT2D`, `Frame.performGabConvolution`,
+`Frame.performEdgePreservingFilter`, `OpsinInverseMatrix.invertXYB`, `PassGroup.invertVarDCT`
+(through `Frame.decodePassGroups`), `ModularStream.applyTransforms`,
+`ModularChannel.inverse{Horizontal,Vertical}Squeeze`, `JXLImage.transfer`. numpy planes stand in for
+the Java `float[][]` / `int[][]` row arrays. Every call runs on the GPU through libjxlatte_amd.so;
+nothing here computes pixels on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import Context, check  # noqa: F401  (re-export)
+
+
+def _p3(planes, ctype):
+    arr = (C.POINTER(ctype) * 3)()
+    for c in range(3):
+        arr[c] = abi.ptr(planes[c], ctype)
+    return arr
+
+
+def _planes(a, dtype):
+    a = np.ascontiguousarray(a, dtype)
+    if a.ndim != 3 or a.shape[0] != 3:
+        raise ValueError("expected planes of shape (3, H, W)")
+    return a
+
+
+class MathHelper:
+    """J/util/MathHelper.java"""
+
+    @staticmethod
+    def inverseDCT2D(ctx, src, transposed=False):
+        src = np.ascontiguousarray(src, np.float32)
+        h, w = src.shape
+        dst = np.empty((w, h) if transposed else (h, w), np.float32)
+        ctx.call("jxl_stage_idct2d", abi.fptr(src), abi.fptr(dst), h, w, 1 if transposed else 0)
+        return dst
+
+    @staticmethod
+    def forwardDCT2D(ctx, src):
+        src = np.ascontiguousarray(src, np.float32)
+        h, w = src.shape
+        dst = np.empty((h, w), np.float32)
+        ctx.call("jxl_stage_fdct2d", abi.fptr(src), abi.fptr(dst), h, w)
+        return dst
+
+
+class OpsinInverseMatrix:
+    """J/color/OpsinInverseMatrix.java"""
+
+    def __init__(self, matrix, opsin_bias, cbrt_opsin_bias):
+        self.matrix = [float(v) for v in matrix]
+        self.opsinBias = [float(v) for v in opsin_bias]
+        self.cbrtOpsinBias = [float(v) for v in cbrt_opsin_bias]
+
+    def invertXYB(self, ctx, buffer, intensityTarget):
+        if len(buffer) < 3:
+            raise ValueError("Can only XYB on 3 channels")  # OpsinInverseMatrix.java:106-107
+        out = np.array(buffer, np.float32, order="C", copy=True)
+        ctx.call("jxl_stage_xyb", _p3(out, C.c_float), out[0].size, abi.f9(*self.matrix), abi.f3(*self.opsinBias),
+                 abi.f3(*self.cbrtOpsinBias), C.c_float(intensityTarget))
+        return out
+
+
+def performColorTransformsYCbCr(ctx, buffer):
+    """YCbCr branch of JXLCodestreamDecoder.performColorTransforms (:270-281)"""
+    out = np.array(buffer, np.float32, order="C", copy=True)
+    ctx.call("jxl_stage_ycbcr", _p3(out, C.c_float), out[0].size)
+    return out
+
+
+def performGabConvolution(ctx, buffer, gab1Weights, gab2Weights):
+    """Frame.performGabConvolution (Frame.java:505-542)"""
+    buf = _planes(buffer, np.float32)
+    out = np.empty_like(buf)
+    ctx.call("jxl_stage_gab", _p3(buf, C.c_float), _p3(out, C.c_float), buf.shape[1], buf.shape[2],
+             abi.f3(*gab1Weights), abi.f3(*gab2Weights))
+    return out
+
+
+def epfInverseSigma(ctx, hfMultiplier, sharpness, globalScaleF, epfSharpLut):
+    """inverse-sigma map of Frame.performEdgePreservingFilter (Frame.java:552-571); raises
+    InvalidBitstreamException for sharpness outside 0..7 (:565-566)."""
+    hf = np.ascontiguousarray(hfMultiplier, np.int32)
+    sh = np.ascontiguousarray(sharpness, np.int32)
+    out = np.empty(hf.shape, np.float32)
+    ctx.call("jxl_stage_epf_sigma", abi.iptr(hf), abi.iptr(sh), hf.shape[0], hf.shape[1], C.c_float(globalScaleF),
+             abi.f8(*epfSharpLut), abi.fptr(out))
+    return out
+
+
+def performEdgePreservingFilter(ctx, buffer, epfIterations, inverseSigma=None, invModularSigma=0.0,
+                                epfChannelScale=(40.0, 5.0, 3.5), epfPass0SigmaScale=0.9, epfPass2SigmaScale=6.5,
+                                epfBorderSadMul=2.0 / 3.0):
+    """Frame.performEdgePreservingFilter iteration loop (Frame.java:583-635)"""
+    buf = _planes(buffer, np.float32)
+    out = np.empty_like(buf)
+    sig = None
+    if inverseSigma is not None:
+        inverseSigma = np.ascontiguousarray(inverseSigma, np.float32)
+        sig = abi.fptr(inverseSigma)
+    ctx.call("jxl_stage_epf", _p3(buf, C.c_float), _p3(out, C.c_float), buf.shape[1], buf.shape[2], epfIterations, sig,
+             C.c_float(invModularSigma), abi.f3(*epfChannelScale), C.c_float(epfPass0SigmaScale),
+             C.c_float(epfPass2SigmaScale), C.c_float(epfBorderSadMul))
+    return out
+
+
+def transfer(ctx, x, tf, maxValue=0):
+    """JXLImage.transferInPlace (+ ImageBuffer.castToIntWithMax when maxValue > 0)"""
+    x = np.ascontiguousarray(x, np.float32)
+    if maxValue > 0:
+        out = np.empty(x.shape, np.int32)
+        ctx.call("jxl_stage_transfer", abi.fptr(x), x.size, tf, maxValue, None, abi.iptr(out))
+    else:
+        out = np.empty(x.shape, np.float32)
+        ctx.call("jxl_stage_transfer", abi.fptr(x), x.size, tf, 0, abi.fptr(out), None)
+    return out
+
+
+class Frame:
+    """VarDCT side of J/frame/Frame.java: decodePassGroups tail (Frame.java:361-374), Gab, EPF and the
+    colour transform of JXLCodestreamDecoder.performColorTransforms, as one device submission.
+
+        fr = Frame(ctx, params, weights, woffs)
+        fr.setLFGroup(g) ...            # HFMetadata / LFCoefficients side info, per LF group
+        fr.putGroup(pass_, group, q)    # HFCoefficients.quantizedCoeffs of one (pass, group)
+        planes = fr.decodeFrame()       # run + read back
+    """
+
+    def __init__(self, ctx, params, weights, woffs):
+        self.ctx = ctx
+        self.params = params
+        self.width, self.height = params.width, params.height
+        ctx.call("jxl_vardct_begin_frame", C.byref(params))
+        weights = np.ascontiguousarray(weights, np.float32)
+        woffs = np.ascontiguousarray(woffs, np.int32)
+        ctx.call("jxl_vardct_set_weights", abi.fptr(weights), weights.size, abi.iptr(woffs))
+
+    def setLFGroup(self, g):
+        d = abi.make_lfgroup_desc(g)
+        self.ctx.call("jxl_vardct_set_lfgroup", C.byref(d))
+
+    def putGroup(self, pass_, group, q):
+        q = [np.ascontiguousarray(a, np.int32) for a in q]
+        pp = (C.POINTER(C.c_int32) * 3)(*[abi.iptr(a) for a in q])
+        strides = (C.c_int32 * 3)(*[a.shape[1] for a in q])
+        self.ctx.call("jxl_vardct_put_group", pass_, group, pp, strides)
+
+    def run(self):
+        """enqueue all stages (asynchronous)"""
+        self.ctx.call("jxl_vardct_run")
+
+    def _out_array(self):
+        es = self.ctx.lib.jxl_vardct_out_elem_size(self.ctx.h)
+        p = self.params
+        as_int = (p.stages & abi.STAGE_OUT) and p.out_format != abi.OUT_F32
+        dt = {4: np.int32 if as_int else np.float32, 2: np.uint16, 1: np.uint8}[es]
+        return np.empty((3, self.height, self.width), dt)
+
+    def readOutput(self):
+        out = self._out_array()
+        pp = (C.c_void_p * 3)(*[out[c].ctypes.data for c in range(3)])
+        self.ctx.call("jxl_vardct_read_output", pp, self.width)
+        return out
+
+    def decodeFrame(self):
+        self.run()
+        return self.readOutput()
+
+    def lastLaunchCount(self):
+        return self.ctx.lib.jxl_vardct_last_launch_count(self.ctx.h)
+
+    @classmethod
+    def from_synth(cls, ctx, frame, stages=None, via_groups=True):
+        """feed a synth.make_vardct_frame dict through the boundary exactly as the Java host would:
+        per LF group side info, per (pass, group) coefficient planes."""
+        from . import synth
+        p = abi.VarDCTParams.from_buffer_copy(frame["params"])
+        if stages is not None:
+            p.stages = stages
+        fr = cls(ctx, p, frame["weights"], frame["woffs"])
+        for g in frame["lfgroups"]:
+            fr.setLFGroup(g)
+        for grp in range(synth.num_groups(frame)):
+            fr.putGroup(0, grp, synth.group_view(frame, grp))
+        return fr
+
+
+class ModularChannel:
+    """J/frame/modular/ModularChannel.java (squeeze part)"""
+
+    @staticmethod
+    def inverseHorizontalSqueeze(ctx, orig, res):
+        orig = np.ascontiguousarray(orig, np.int32)
+        res = np.ascontiguousarray(res, np.int32)
+        h, aw = orig.shape
+        if res.shape[0] != h:
+            raise ValueError("Corrupted squeeze transform")  # ModularChannel.java:363-366
+        out = np.empty((h, aw + res.shape[1]), np.int32)
+        ctx.call("jxl_stage_inv_hsqueeze", abi.iptr(orig), aw, abi.iptr(res), res.shape[1], h, abi.iptr(out))
+        return out
+
+    @staticmethod
+    def inverseVerticalSqueeze(ctx, orig, res):
+        orig = np.ascontiguousarray(orig, np.int32)
+        res = np.ascontiguousarray(res, np.int32)
+        ah, w = orig.shape
+        if res.shape[1] != w:
+            raise RuntimeError("Corrupted squeeze transform")  # ModularChannel.java:391-394 (IllegalStateException)
+        out = np.empty((ah + res.shape[0], w), np.int32)
+        ctx.call("jxl_stage_inv_vsqueeze", abi.iptr(orig), ah, abi.iptr(res), res.shape[0], w, abi.iptr(out))
+        return out
+
+
+class ModularStream:
+    """Transform part of J/frame/modular/ModularStream.java: the channel list as decoded by the host
+    (averages + residuals) plus the squeeze parameters; applyTransforms() undoes Squeeze (and RCT)."""
+
+    def __init__(self, ctx, channels, squeezeParams, rctType=-1, rctBegin=0):
+        self.ctx = ctx
+        self.channels = [np.ascontiguousarray(c, np.int32) for c in channels]
+        self.sp = [tuple(int(v) for v in s) for s in squeezeParams]
+        self.rctType, self.rctBegin = rctType, rctBegin
+        self.transformed = False
+        self._begun = False
+
+    @staticmethod
+    def defaultSqueezeParams(shapes, nbMeta=0):
+        """ModularStream.java:110-131 through the C-ABI (shapes: list of (h, w))"""
+        from ._lib import load
+        ws = np.array([s[1] for s in shapes], np.int32)
+        hs = np.array([s[0] for s in shapes], np.int32)
+        out = (abi.SqueezeParam * 64)()
+        n = load().jxl_modular_default_squeeze_params(abi.iptr(ws), abi.iptr(hs), len(shapes), nbMeta, out, 64)
+        if n < 0:
+            raise ValueError("status %d" % n)
+        return [out[i].as_tuple() for i in range(n)]
+
+    @staticmethod
+    def squeezedShapes(shapes, sp):
+        from ._lib import load
+        ws = np.array([s[1] for s in shapes], np.int32)
+        hs = np.array([s[0] for s in shapes], np.int32)
+        cap = len(shapes) + sum(p[3] for p in sp) + 1
+        ow, oh = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = load().jxl_modular_squeezed_shapes(abi.iptr(ws), abi.iptr(hs), len(shapes), abi.make_squeeze_params(sp), len(sp),
+                                               abi.iptr(ow), abi.iptr(oh), cap)
+        if n < 0:
+            raise ValueError("status %d" % n)
+        return [(int(oh[i]), int(ow[i])) for i in range(n)]
+
+    def begin(self):
+        ca = abi.make_channels(self.channels)
+        self.ctx.call("jxl_modular_begin", ca, len(self.channels), abi.make_squeeze_params(self.sp), len(self.sp),
+                      self.rctType, self.rctBegin)
+        self._begun = True
+
+    def run(self):
+        if not self._begun:
+            self.begin()
+        self.ctx.call("jxl_modular_run")
+
+    def getDecodedBuffer(self):
+        lib, h = self.ctx.lib, self.ctx.h
+        outs = []
+        for i in range(lib.jxl_modular_out_count(h)):
+            w, hh = C.c_int32(), C.c_int32()
+            check(h, lib.jxl_modular_out_shape(h, i, C.byref(w), C.byref(hh)))
+            a = np.empty((hh.value, w.value), np.int32)
+            self.ctx.call("jxl_modular_read_channel", i, abi.iptr(a) if a.size else None)
+            outs.append(a)
+        return outs
+
+    def applyTransforms(self):
+        """ModularStream.applyTransforms (ModularStream.java:224-380): idempotent like the reference"""
+        if self.transformed:
+            return self.channels
+        self.transformed = True
+        self.run()
+        self.channels = self.getDecodedBuffer()
+        return self.channels
+
+
+def rct(ctx, v, rctType):
+    """RCT branch of ModularStream.applyTransforms (ModularStream.java:255-326)"""
+    out = np.array(v, np.int32, order="C", copy=True)
+    pp = (C.POINTER(C.c_int32) * 3)(*[abi.iptr(out[c]) for c in range(3)])
+    ctx.call("jxl_stage_rct", pp, out[0].size, rctType)
+    return out
+
+
+def modularToFloat(ctx, a, b, scale):
+    """Frame.decodeFrame modular -> float buffer (Frame.java:437-448)"""
+    a = np.ascontiguousarray(a, np.int32)
+    out = np.empty(a.shape, np.float32)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.int32)
+        bp = abi.iptr(b)
+    ctx.call("jxl_stage_modular_to_float", abi.iptr(a), bp, a.size, C.c_float(scale), abi.fptr(out))
+    return out
