@@ -141,6 +141,9 @@ const char* jxl_version(void);
 jxl_status jxl_ctx_synchronize(jxl_ctx* ctx);
 /* HIP stream handle (hipStream_t) the ctx launches on; for event timing by callers. */
 void*      jxl_ctx_stream(jxl_ctx* ctx);
+/* Launch on a caller-owned HIP stream instead (e.g. several frame contexts sharing one stream, or
+ * torch's current stream). The ctx no longer owns a stream after this call. */
+jxl_status jxl_ctx_set_stream(jxl_ctx* ctx, void* hip_stream);
 
 /* ---- VarDCT frame path: replaces Frame.decodePassGroups tail .. performColorTransforms */
 /* call order: begin_frame, set_weights, set_lfgroup* , put_group*, (run | finish_frame) */
@@ -169,8 +172,8 @@ jxl_status jxl_vardct_copy_output_device(jxl_ctx* ctx, void* dst_device);
 int32_t    jxl_vardct_out_elem_size(const jxl_ctx* ctx);
 /* number of kernel launches the last jxl_vardct_run enqueued (diagnostics) */
 int32_t    jxl_vardct_last_launch_count(const jxl_ctx* ctx);
-/* time the last jxl_vardct_run's dominant kernel(s) with HIP events on the ctx stream:
- * which = 0 whole run, 1 IDCT stage, 2 restoration+colour stage. ms out. */
+/* HIP-event timing on the ctx stream, averaged over the runs recorded since timing was enabled
+ * (ring of the 32 most recent): which = 0 whole run, 1 IDCT stage, 2 restoration+colour stage. */
 jxl_status jxl_vardct_last_stage_ms(jxl_ctx* ctx, int32_t which, float* ms);
 jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* ctx, int32_t on);
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "jxl_version": (C.c_char_p, []),
     "jxl_ctx_synchronize": (i32, [vp]),
     "jxl_ctx_stream": (vp, [vp]),
+    "jxl_ctx_set_stream": (i32, [vp, vp]),
     "jxl_vardct_begin_frame": (i32, [vp, C.POINTER(abi.VarDCTParams)]),
     "jxl_vardct_set_weights": (i32, [vp, pf, C.c_size_t, pi]),
     "jxl_vardct_set_lfgroup": (i32, [vp, C.POINTER(abi.LFGroupDesc)]),

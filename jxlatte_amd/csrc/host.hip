@@ -87,8 +87,10 @@ struct jxl_ctx {
     int result_elem = 4;
     int last_launches = 0;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    static constexpr int kEvSlots = 32;
+    hipEvent_t ev[kEvSlots][3] = {};  // ring of (start, after IDCT stage, end) per run
+    int ev_runs = 0;                  // runs recorded since timing was enabled
+    bool owns_stream = true;
 
     // ---- Modular state
     std::vector<DevBuf> mod_bufs;
@@ -335,7 +337,8 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
         jxl_ctx_destroy(c);
         return fail(nullptr, JXL_ERR_DEVICE, "cannot upload the cosine LUT");
     }
-    for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < jxl_ctx::kEvSlots; i++)
+        for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     *out = c;
     return JXL_OK;
 }
@@ -351,9 +354,10 @@ void jxl_ctx_destroy(jxl_ctx* c) {
         c->coeff[i].release(); c->lf[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
     }
     for (auto& b : c->mod_bufs) b.release();
-    for (int i = 0; i < 4; i++)
-        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < jxl_ctx::kEvSlots; i++)
+        for (int j = 0; j < 3; j++)
+            if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -365,6 +369,16 @@ jxl_status jxl_ctx_synchronize(jxl_ctx* c) {
 }
 
 void* jxl_ctx_stream(jxl_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+jxl_status jxl_ctx_set_stream(jxl_ctx* c, void* stream) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)stream;
+    c->owns_stream = false;
+    return JXL_OK;
+}
 
 // ---- VarDCT frame ---------------------------------------------------------------------------------
 jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
@@ -405,7 +419,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     c->lfg_set.assign(nl, 0);
     c->tables_dirty = true;
     c->frame_open = true;
-    c->ev_valid = false;
+    c->ev_runs = 0;
     c->result[0] = c->result[1] = c->result[2] = nullptr;
     return JXL_OK;
 }
@@ -500,6 +514,7 @@ jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const i
 jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* c, int32_t on) {
     if (!c) return JXL_ERR_INVALID_ARGUMENT;
     c->timing = on != 0;
+    c->ev_runs = 0;
     return JXL_OK;
 }
 
@@ -514,7 +529,8 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
     int launches = 0;
     float* A[3] = {c->planeA[0].as<float>(), c->planeA[1].as<float>(), c->planeA[2].as<float>()};
     float* B[3] = {c->planeB[0].as<float>(), c->planeB[1].as<float>(), c->planeB[2].as<float>()};
-    if (c->timing) (void)hipEventRecord(c->ev[0], s);
+    hipEvent_t* evs = c->ev[c->ev_runs % jxl_ctx::kEvSlots];
+    if (c->timing) (void)hipEventRecord(evs[0], s);
     if (p.stages & JXL_STAGE_IDCT) {
         DevFrame f;
         fill_dev_frame(c, f);
@@ -530,7 +546,7 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         }
         if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
     }
-    if (c->timing) (void)hipEventRecord(c->ev[1], s);
+    if (c->timing) (void)hipEventRecord(evs[1], s);
     float** cur = A;
     float** oth = B;
     const bool do_gab = (p.stages & JXL_STAGE_GAB) && p.gab;
@@ -607,8 +623,8 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         }
     }
     if (c->timing) {
-        (void)hipEventRecord(c->ev[2], s);
-        c->ev_valid = true;
+        (void)hipEventRecord(evs[2], s);
+        c->ev_runs++;
     }
     c->last_launches = launches;
     hipError_t e = hipGetLastError();
@@ -619,10 +635,17 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
 jxl_status jxl_vardct_last_stage_ms(jxl_ctx* c, int32_t which, float* ms) {
     jxl_status st = bind(c);
     if (st) return st;
-    if (!ms || !c->ev_valid) return fail(c, JXL_ERR_STATE, "enable stage timing and run first");
-    HIP_TRY(c, hipEventSynchronize(c->ev[2]));
+    if (!ms || c->ev_runs <= 0) return fail(c, JXL_ERR_STATE, "enable stage timing and run first");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int n = std::min(c->ev_runs, (int)jxl_ctx::kEvSlots);
     const int a = which == 2 ? 1 : 0, b = which == 1 ? 1 : 2;
-    HIP_TRY(c, hipEventElapsedTime(ms, c->ev[a], c->ev[b]));
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        float t = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->ev[i][a], c->ev[i][b]));
+        sum += t;
+    }
+    *ms = (float)(sum / n);
     return JXL_OK;
 }
 

@@ -229,22 +229,24 @@ def make_vardct_frame(width, height, seed=1234, mix="default", aligned=True, par
         box = (cs[5:, 5:] - cs[:-5, 5:] - cs[5:, :-5] + cs[:-5, :-5]) / 25.0
         lf[c] = (0.1 * (c == 1) + 0.02 * (c != 1) + 0.1 * box[:bh, :bw]).astype(F)
 
-    # quantised HF coefficients
+    # quantised HF coefficients: zero with p = 1 - nonzero_p, else round(Laplace(0, scale/(1+4r))), r = radial
+    # frequency normalised to the block size; LLF corner positions stay 0 (the decoder never writes them)
     up = lambda m: np.repeat(np.repeat(m, 8, 0), 8, 1)
-    yy = np.arange(height, dtype=np.int32)[:, None] - up(cell_oy) * 8
-    xx = np.arange(width, dtype=np.int32)[None, :] - up(cell_ox) * 8
-    hh, ww = up(cell_h), up(cell_w)
-    r = np.sqrt((yy / hh) ** 2 + (xx / ww) ** 2)
-    scale = coeff_scale / (1.0 + 4.0 * r)
-    llf = (yy < hh // 8) & (xx < ww // 8)
+    yy = (np.arange(height, dtype=np.int32)[:, None] - up(cell_oy) * 8).astype(F)
+    xx = (np.arange(width, dtype=np.int32)[None, :] - up(cell_ox) * 8).astype(F)
+    hh, ww = up(cell_h).astype(F), up(cell_w).astype(F)
+    llf = (yy * 8 < hh) & (xx * 8 < ww)
+    yy /= hh
+    xx /= ww
+    scale = (F(coeff_scale) / (F(1.0) + F(4.0) * np.sqrt(yy * yy + xx * xx))).ravel()
+    del yy, xx, hh, ww
+    notllf = ~llf.ravel()
     coeff = np.zeros((3, height, width), np.int32)
     for c in range(3):
-        lap = rng.laplace(0.0, 1.0, size=(height, width)) * scale * (1.0 if c == 1 else 0.5)
-        keep = rng.random((height, width)) < nonzero_p
-        q = np.rint(lap).astype(np.int32)
-        q[~keep] = 0
-        q[llf] = 0
-        coeff[c] = q
+        keep = (rng.random(height * width, dtype=F) < F(nonzero_p)) & notllf
+        idx = np.flatnonzero(keep)
+        lap = rng.laplace(0.0, 1.0, size=idx.size) * scale[idx] * (1.0 if c == 1 else 0.5)
+        coeff[c].ravel()[idx] = np.rint(lap).astype(np.int32)
 
     weights, woffs = hfglobal.default_weights()
     p = params if params is not None else default_params(width, height, **param_kw)
