@@ -1,10 +1,423 @@
-// Fused restoration + colour tile kernel (Gab -> EPF -> XYB -> transfer) -- placeholder until the
-// LDS-tiled version lands: reports "not covered" so the host uses the stage kernels of k_restore.hip.
+// Fused restoration + colour tile kernel for gfx950:
+//   Gaborish -> EPF iteration(s) -> XYB->linear -> (transfer + quantise) in ONE launch, one read and
+//   one write of the frame planes; all intermediates live in LDS.
+//
+// Replaces the same reference functions as k_restore.hip (Frame.java:505-679,
+// OpsinInverseMatrix.java:105-142, JXLImage.java:244-258, ImageBuffer.java:129-147) and is checked
+// bit-for-bit against them through the oracle AND against the stage kernels.
+//
+// Geometry (template <GAB, ITERS>): the most expensive stage -- the first EPF iteration that runs -- is
+// computed on a 64x32 window = 256 threads x (4 wide x 2 tall) register patches. Later iterations
+// shrink the window by their radius (iteration 1: 2 px of input halo, iteration 2: 1, iteration 0: 3),
+// Gaborish adds 1. E.g. the default (Gab + iterations 1,2): input tile 70x38 -> Gab 68x36 -> EPF1 64x32
+// -> EPF2 62x30 output tile. Two LDS buffers (ping-pong) of 3 planes each.
+//
+// Exactness: per pixel the EPF distance is the reference's strictly sequential sum
+//   dist = (((0 + |a-b|*s0) + ...)            channel-major, cross order (0,0),(0,-1),(0,1),(-1,0),(1,0)
+// Every |P(u) - P(v)| * scale term is written with canonically ordered operands (|x-y| == |y-x| exactly)
+// so the compiler's value numbering shares the terms between the pixels and taps of a patch instead of
+// recomputing them. The centre tap has distance exactly 0 and weight exactly 1 for finite samples (the
+// IDCT output is finite), so it is folded: sumWeights starts at 1, sumChannels at the centre sample.
+// Frame edges: Gab reads clamped coordinates, EPF reads mirrored ones (MathHelper.mirrorCoordinate);
+// edge tiles re-create that by copying mirrored positions inside LDS after each stage.
 #include "jxl_internal.h"
+
 namespace jxl {
+
+namespace {
+
+__device__ __forceinline__ int mirror_c(int c, int size) {
+    while (c < 0 || c >= size) {
+        const int tc = ~c;
+        c = tc >= 0 ? tc : (size << 1) + tc;
+    }
+    return c;
+}
+
+template <bool GAB, int ITERS>
+struct Geo {
+    static constexpr int RG = GAB ? 1 : 0;
+    static constexpr int R0 = ITERS == 3 ? 3 : 0;
+    static constexpr int R1 = ITERS >= 1 ? 2 : 0;
+    static constexpr int R2 = ITERS >= 2 ? 1 : 0;
+    static constexpr int SHR = ITERS == 3 ? (R1 + R2) : ITERS == 2 ? R2 : 0;  // window -> output tile
+    static constexpr int OW = 64 - 2 * SHR, OH = 32 - 2 * SHR;               // output tile
+    static constexpr int RE = R0 + R1 + R2;
+    static constexpr int RT = RE + RG;                                        // input halo
+    static constexpr int IW = OW + 2 * RT, IH = OH + 2 * RT;                  // input tile
+    static constexpr int SW = IW + 3;                                         // LDS row stride (patch over-read <= 3)
+    static constexpr int SH = IH + 1;
+    static constexpr int PLANE = SW * SH;
+    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * 3 * PLANE + 16 * 16);
+};
+
+// Java (int)float
+__device__ __forceinline__ int32_t f2i_java(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+__device__ __forceinline__ float tf_pq_f(float f) {
+    const double d = pow((double)f, 0.159423828125);
+    return (float)pow((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375);
+}
+__device__ __forceinline__ float tf_srgb_f(float f) {
+    if (f < 0.00313066844250063f) return f * 12.92f;
+    return 1.055f * (float)pow((double)f, 0.4166666666666667) + -0.055f;
+}
+
+// canonical |P[u] - P[v]| * s: operands ordered by index so equal terms are literally the same expression
+template <int PS>
+__device__ __forceinline__ float adiff(const float* p, int u, int v, float s) {
+    return u < v ? fabsf(p[u] - p[v]) * s : fabsf(p[v] - p[u]) * s;
+}
+
+// One EPF iteration (Frame.java:583-635) on a 4x2 patch whose top-left sample is (ry, rx) in region
+// coordinates of src (3 planes, stride SW). Results for the 8 pixels go to res[c][py*4+px].
+// ITER: 0 = 13 taps with cross distances, 1 = 5 taps with cross distances, 2 = 5 taps single-pixel.
+template <int ITER, int SW, int PLANE>
+__device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry, int rx, const float* s_inv /*[8]*/,
+                                          const bool* border /*[8]*/, const EpfParams& ep, float res[3][8]) {
+    constexpr int R = ITER == 0 ? 3 : ITER == 1 ? 2 : 1;  // neighbourhood radius
+    constexpr int NW = 4 + 2 * R, NH = 2 + 2 * R;
+    constexpr int NT = ITER == 0 ? 12 : 4;  // non-centre taps
+    // (dy, dx) in the reference's order, centre tap folded (Frame.java:44-55)
+    constexpr int TY[12] = {0, 0, -1, 1, -1, 1, 1, -1, 0, 0, 2, -2};
+    constexpr int TX[12] = {-1, 1, 0, 0, 1, 1, -1, -1, -2, 2, 0, 0};
+    constexpr int QY[5] = {0, 0, 0, -1, 1};
+    constexpr int QX[5] = {0, -1, 1, 0, 0};
+
+    float dist[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) dist[i][t] = 0.0f;
+
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        // neighbourhood of this channel in registers; only the diamond of radius R around the patch is
+        // ever referenced, the compiler drops the unused corner loads
+        float nb[NH * NW];
+        const float* pc = src + c * PLANE + (ry - R) * SW + (rx - R);
+#pragma unroll
+        for (int y = 0; y < NH; y++)
+#pragma unroll
+            for (int x = 0; x < NW; x++) nb[y * NW + x] = pc[y * SW + x];
+        const float sc = ep.channel_scale[c];
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                const int cy = py + R, cx = px + R;  // centre inside nb
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (ITER == 2) {  // epfDistance2 (:657-669): single pixel
+                        dist[py * 4 + px][t] =
+                            dist[py * 4 + px][t] + adiff<NW>(nb, cy * NW + cx, (cy + TY[t]) * NW + cx + TX[t], sc);
+                    } else {  // epfDistance1 (:638-655): 5-point cross
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const int u = (cy + QY[q]) * NW + cx + QX[q];
+                            const int v = (cy + TY[t] + QY[q]) * NW + cx + TX[t] + QX[q];
+                            dist[py * 4 + px][t] = dist[py * 4 + px][t] + adiff<NW>(nb, u, v, sc);
+                        }
+                    }
+                }
+            }
+    }
+    // weights (epfWeight, :671-679), in place of the distances
+    float sumW[8];
+    bool skip[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float s = s_inv[i];
+        skip[i] = (s != s) || (s > (1.0f / 0.3f));  // :608-612
+        float sw = 0.0f + 1.0f;                     // centre tap: dist 0 -> weight 1 (finite samples)
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float d = dist[i][t];
+            if (border[i]) d = d * ep.border_sad_mul;
+            const float v = 1.0f - d * ep.sigma_scale * s;
+            const float w = v < 0.0f ? 0.0f : v;
+            dist[i][t] = w;
+            sw = sw + w;
+        }
+        sumW[i] = sw;
+    }
+    // weighted sums per channel (:615-626): tap radius RT2 only
+    constexpr int RT2 = ITER == 0 ? 2 : 1;
+    constexpr int MW = 4 + 2 * RT2, MH = 2 + 2 * RT2;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float nb[MH * MW];
+        const float* pc = src + c * PLANE + (ry - RT2) * SW + (rx - RT2);
+#pragma unroll
+        for (int y = 0; y < MH; y++)
+#pragma unroll
+            for (int x = 0; x < MW; x++) nb[y * MW + x] = pc[y * SW + x];
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                const int i = py * 4 + px;
+                const int cy = py + RT2, cx = px + RT2;
+                float sc = 0.0f + nb[cy * MW + cx] * 1.0f;
+#pragma unroll
+                for (int t = 0; t < NT; t++) sc = sc + nb[(cy + TY[t]) * MW + cx + TX[t]] * dist[i][t];
+                res[c][i] = skip[i] ? nb[cy * MW + cx] : sc / sumW[i];
+            }
+    }
+}
+
+struct TileCtx {
+    int ix0, iy0;  // frame coordinates of region (0,0)
+    int W, H;
+    bool edge;
+};
+
+// run one EPF iteration over the output region [m, IH-m) x [m, IW-m) of the tile
+template <int ITER, typename G, bool LAST, typename Sink>
+__device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* __restrict__ dst, int m, const TileCtx& tc,
+                                          const float* __restrict__ sig, int scy0, int scx0, const EpfParams& ep, Sink sink) {
+    constexpr int SW = G::SW, PLANE = G::PLANE;
+    const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
+    const int pcols = (rw + 3) >> 2, prows = (rh + 1) >> 1;
+    for (int pi = threadIdx.x; pi < pcols * prows; pi += 256) {
+        const int ry = m + (pi / pcols) * 2, rx = m + (pi % pcols) * 4;
+        float s_inv[8];
+        bool border[8];
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                int gy = tc.iy0 + ry + py, gx = tc.ix0 + rx + px;
+                const int modY = gy & 7, modX = gx & 7;
+                border[py * 4 + px] = modY == 0 || modY == 7 || modX == 0 || modX == 7;
+                gy = min(max(gy, 0), tc.H - 1);  // out-of-frame positions are recomputed by the mirror fix-up
+                gx = min(max(gx, 0), tc.W - 1);
+                s_inv[py * 4 + px] = sig[((gy >> 3) - scy0) * 16 + ((gx >> 3) - scx0)];
+            }
+        float res[3][8];
+        epf_patch<ITER, SW, PLANE>(src, ry, rx, s_inv, border, ep, res);
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                const int y = ry + py, x = rx + px;
+                if (y < G::IH - m && x < G::IW - m) {
+                    if (LAST) sink(y, x, res[0][py * 4 + px], res[1][py * 4 + px], res[2][py * 4 + px]);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) dst[c * PLANE + y * SW + x] = res[c][py * 4 + px];
+                    }
+                }
+            }
+    }
+}
+
+// after a non-final stage on an edge tile: positions of the region outside the frame take the value of
+// their mirrored in-frame position (what a mirrored read of the full-frame plane would return)
+template <typename G>
+__device__ __forceinline__ void mirror_fixup(float* __restrict__ buf, int m, int rem, const TileCtx& tc) {
+    const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
+    __syncthreads();
+    for (int i = threadIdx.x; i < rw * rh; i += 256) {
+        const int y = m + i / rw, x = m + i % rw;
+        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
+        const bool outside = gy < 0 || gy >= tc.H || gx < 0 || gx >= tc.W;
+        // only positions within the radius the remaining stages can reach from an in-frame pixel matter
+        const bool near = gy >= -rem && gy < tc.H + rem && gx >= -rem && gx < tc.W + rem;
+        if (outside && near) {
+            const int my = mirror_c(gy, tc.H) - tc.iy0, mx = mirror_c(gx, tc.W) - tc.ix0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) buf[c * G::PLANE + y * G::SW + x] = buf[c * G::PLANE + my * G::SW + mx];
+        }
+    }
+}
+
+struct FusedArgs {
+    const float* in[3];
+    void* out[3];
+    const int32_t* hf_mul;
+    const int32_t* sharpness;
+    int W, H, bw;
+    RestoreParams p;
+};
+
+template <bool GAB, int ITERS>
+__global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
+    using G = Geo<GAB, ITERS>;
+    extern __shared__ float lds[];
+    float* A = lds;
+    float* B = lds + 3 * G::PLANE;
+    float* sig = lds + 6 * G::PLANE;  // [16][16] inverse sigma of the cells under the tile
+    const int W = a.W, H = a.H;
+    TileCtx tc;
+    tc.W = W;
+    tc.H = H;
+    const int ox = blockIdx.x * G::OW, oy = blockIdx.y * G::OH;
+    tc.ix0 = ox - G::RT;
+    tc.iy0 = oy - G::RT;
+    tc.edge = tc.ix0 < 0 || tc.iy0 < 0 || tc.ix0 + G::IW > W || tc.iy0 + G::IH > H;
+
+    // inverse sigma per cell (Frame.java:552-571)
+    const int scy0 = max(tc.iy0, 0) >> 3, scx0 = max(tc.ix0, 0) >> 3;
+    if (ITERS > 0) {
+        const int cy = scy0 + (threadIdx.x >> 4), cx = scx0 + (threadIdx.x & 15);
+        float v = 0.0f;
+        if (cy < ((H + 7) >> 3) && cx < a.bw) {
+            const int sharp = a.sharpness[cy * a.bw + cx] & 7;
+            const float sigma = a.p.global_scale_f * a.p.sharp_lut[sharp] / (float)a.hf_mul[cy * a.bw + cx];
+            v = 1.0f / sigma;
+        }
+        sig[threadIdx.x] = v;
+    }
+    // load the input tile: clamped coordinates feed Gab, mirrored ones feed EPF directly
+    for (int i = threadIdx.x; i < G::IW * G::IH; i += 256) {
+        const int y = i / G::IW, x = i % G::IW;
+        int gy = tc.iy0 + y, gx = tc.ix0 + x;
+        if (tc.edge) {
+            if (GAB) {
+                gy = min(max(gy, 0), H - 1);
+                gx = min(max(gx, 0), W - 1);
+            } else {
+                gy = mirror_c(gy, H);
+                gx = mirror_c(gx, W);
+            }
+        }
+        const int64_t g = (int64_t)gy * W + gx;
+#pragma unroll
+        for (int c = 0; c < 3; c++) A[c * G::PLANE + y * G::SW + x] = a.in[c][g];
+    }
+    __syncthreads();
+    float* cur = A;
+    float* oth = B;
+    int m = 0;
+    if (GAB) {  // Frame.performGabConvolution (:505-542)
+        m = 1;
+        const int rw = G::IW - 2, rh = G::IH - 2;
+        for (int i = threadIdx.x; i < rw * rh; i += 256) {
+            const int y = 1 + i / rw, x = 1 + i % rw;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float* p = cur + c * G::PLANE + y * G::SW + x;
+                const float adj = p[-1] + p[1] + p[-G::SW] + p[G::SW];
+                const float diag = p[-G::SW - 1] + p[-G::SW + 1] + p[G::SW - 1] + p[G::SW + 1];
+                oth[c * G::PLANE + y * G::SW + x] = a.p.gab_base[c] * p[0] + a.p.gab_adj[c] * adj + a.p.gab_diag[c] * diag;
+            }
+        }
+        if (tc.edge && ITERS > 0) mirror_fixup<G>(oth, m, G::RE, tc);
+        __syncthreads();
+        float* t = cur; cur = oth; oth = t;
+    }
+
+    // final sink: XYB + transfer/quantise + global store
+    auto sink = [&](int y, int x, float v0, float v1, float v2) {
+        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
+        if (gy >= H || gx >= W) return;
+        if (a.p.xyb) {
+            const XybParams& xp = a.p.xybp;
+            const float gammaL = v1 + v0 + xp.cob[0];
+            const float gammaM = v1 - v0 + xp.cob[1];
+            const float gammaS = v2 + xp.cob[2];
+            const float mixL = (gammaL * gammaL) * gammaL + xp.ob[0];
+            const float mixM = (gammaM * gammaM) * gammaM + xp.ob[1];
+            const float mixS = (gammaS * gammaS) * gammaS + xp.ob[2];
+            v0 = xp.sm[0] * mixL + xp.sm[1] * mixM + xp.sm[2] * mixS;
+            v1 = xp.sm[3] * mixL + xp.sm[4] * mixM + xp.sm[5] * mixS;
+            v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
+        }
+        const int64_t g = (int64_t)gy * W + gx;
+        float v[3] = {v0, v1, v2};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float t = v[c];
+            if (a.p.transfer == JXL_TRANSFER_PQ) t = tf_pq_f(t);
+            else if (a.p.transfer == JXL_TRANSFER_SRGB) t = tf_srgb_f(t);
+            if (a.p.max_value > 0) {
+                int32_t q = f2i_java(t * (float)a.p.max_value + 0.5f);
+                q = q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
+                if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+                else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
+                else ((int32_t*)a.out[c])[g] = q;
+            } else {
+                ((float*)a.out[c])[g] = t;
+            }
+        }
+    };
+
+    if (ITERS == 0) {
+        const int mm = m;
+        for (int i = threadIdx.x; i < G::OW * G::OH; i += 256) {
+            const int y = mm + i / G::OW, x = mm + i % G::OW;
+            sink(y, x, cur[y * G::SW + x], cur[G::PLANE + y * G::SW + x], cur[2 * G::PLANE + y * G::SW + x]);
+        }
+        return;
+    }
+    if (ITERS == 3) {
+        m += 3;
+        epf_stage<0, G, false>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
+        if (tc.edge) mirror_fixup<G>(oth, m, G::R1 + G::R2, tc);
+        __syncthreads();
+        float* t = cur; cur = oth; oth = t;
+    }
+    m += 2;
+    if (ITERS >= 2) {
+        epf_stage<1, G, false>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
+        if (tc.edge) mirror_fixup<G>(oth, m, G::R2, tc);
+        __syncthreads();
+        float* t = cur; cur = oth; oth = t;
+        m += 1;
+        epf_stage<2, G, true>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[2], sink);
+    } else {
+        epf_stage<1, G, true>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
+    }
+}
+
+template <bool GAB, int ITERS>
+void launch_t(const FusedArgs& a, hipStream_t s) {
+    using G = Geo<GAB, ITERS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused<GAB, ITERS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        attr_set = true;
+    }
+    const dim3 grid((a.W + G::OW - 1) / G::OW, (a.H + G::OH - 1) / G::OH);
+    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS>), grid, dim3(256), G::LDS_BYTES, s, a);
+}
+
+}  // namespace
+
 bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                           const int32_t* sharpness, const RestoreParams& p, hipStream_t s) {
-    (void)in; (void)out; (void)h; (void)w; (void)hf_mul; (void)sharpness; (void)p; (void)s;
-    return false;
+    if (w < 8 || h < 8) return false;  // mirror fix-up assumes at most one reflection within the halo
+    if (p.epf_iters > 0 && (!hf_mul || !sharpness)) return false;
+    FusedArgs a;
+    for (int c = 0; c < 3; c++) {
+        a.in[c] = in[c];
+        a.out[c] = out[c];
+    }
+    a.hf_mul = hf_mul;
+    a.sharpness = sharpness;
+    a.W = w;
+    a.H = h;
+    a.bw = (w + 7) >> 3;
+    a.p = p;
+    const int it = p.epf_iters;
+    if (p.gab) {
+        if (it == 0) launch_t<true, 0>(a, s);
+        else if (it == 1) launch_t<true, 1>(a, s);
+        else if (it == 2) launch_t<true, 2>(a, s);
+        else launch_t<true, 3>(a, s);
+    } else {
+        if (it == 0) launch_t<false, 0>(a, s);
+        else if (it == 1) launch_t<false, 1>(a, s);
+        else if (it == 2) launch_t<false, 2>(a, s);
+        else launch_t<false, 3>(a, s);
+    }
+    return true;
 }
+
 }  // namespace jxl
