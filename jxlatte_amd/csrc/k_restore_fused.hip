@@ -76,11 +76,12 @@ __device__ __forceinline__ float adiff(const float* p, int u, int v, float s) {
 // One EPF iteration (Frame.java:583-635) on a 4x2 patch whose top-left sample is (ry, rx) in region
 // coordinates of src (3 planes, stride SW). Results for the 8 pixels go to res[c][py*4+px].
 // ITER: 0 = 13 taps with cross distances, 1 = 5 taps with cross distances, 2 = 5 taps single-pixel.
-template <int ITER, int SW, int PLANE>
-__device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry, int rx, const float* s_inv /*[8]*/,
-                                          const bool* border /*[8]*/, const EpfParams& ep, float res[3][8]) {
+template <int ITER, int SW, int PLANE, int PH>
+__device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry, int rx, const float* s_inv /*[NP]*/,
+                                          const bool* border /*[NP]*/, const EpfParams& ep, float res[3][4 * PH]) {
+    constexpr int NP = 4 * PH;  // pixels per patch
     constexpr int R = ITER == 0 ? 3 : ITER == 1 ? 2 : 1;  // neighbourhood radius
-    constexpr int NW = 4 + 2 * R, NH = 2 + 2 * R;
+    constexpr int NW = 4 + 2 * R, NH = PH + 2 * R;
     constexpr int NT = ITER == 0 ? 12 : 4;  // non-centre taps
     // (dy, dx) in the reference's order, centre tap folded (Frame.java:44-55)
     constexpr int TY[12] = {0, 0, -1, 1, -1, 1, 1, -1, 0, 0, 2, -2};
@@ -88,9 +89,9 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
     constexpr int QY[5] = {0, 0, 0, -1, 1};
     constexpr int QX[5] = {0, -1, 1, 0, 0};
 
-    float dist[8][NT];
+    float dist[NP][NT];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < NP; i++)
 #pragma unroll
         for (int t = 0; t < NT; t++) dist[i][t] = 0.0f;
 
@@ -106,7 +107,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
             for (int x = 0; x < NW; x++) nb[y * NW + x] = pc[y * SW + x];
         const float sc = ep.channel_scale[c];
 #pragma unroll
-        for (int py = 0; py < 2; py++)
+        for (int py = 0; py < PH; py++)
 #pragma unroll
             for (int px = 0; px < 4; px++) {
                 const int cy = py + R, cx = px + R;  // centre inside nb
@@ -127,10 +128,10 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
             }
     }
     // weights (epfWeight, :671-679), in place of the distances
-    float sumW[8];
-    bool skip[8];
+    float sumW[NP];
+    bool skip[NP];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NP; i++) {
         const float s = s_inv[i];
         skip[i] = (s != s) || (s > (1.0f / 0.3f));  // :608-612
         float sw = 0.0f + 1.0f;                     // centre tap: dist 0 -> weight 1 (finite samples)
@@ -147,7 +148,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
     }
     // weighted sums per channel (:615-626): tap radius RT2 only
     constexpr int RT2 = ITER == 0 ? 2 : 1;
-    constexpr int MW = 4 + 2 * RT2, MH = 2 + 2 * RT2;
+    constexpr int MW = 4 + 2 * RT2, MH = PH + 2 * RT2;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float nb[MH * MW];
@@ -157,7 +158,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
 #pragma unroll
             for (int x = 0; x < MW; x++) nb[y * MW + x] = pc[y * SW + x];
 #pragma unroll
-        for (int py = 0; py < 2; py++)
+        for (int py = 0; py < PH; py++)
 #pragma unroll
             for (int px = 0; px < 4; px++) {
                 const int i = py * 4 + px;
@@ -177,18 +178,19 @@ struct TileCtx {
 };
 
 // run one EPF iteration over the output region [m, IH-m) x [m, IW-m) of the tile
-template <int ITER, typename G, bool LAST, typename Sink>
+template <int ITER, typename G, bool LAST, int PH, typename Sink>
 __device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* __restrict__ dst, int m, const TileCtx& tc,
                                           const float* __restrict__ sig, int scy0, int scx0, const EpfParams& ep, Sink sink) {
     constexpr int SW = G::SW, PLANE = G::PLANE;
     const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
-    const int pcols = (rw + 3) >> 2, prows = (rh + 1) >> 1;
-    for (int pi = threadIdx.x; pi < pcols * prows; pi += 256) {
-        const int ry = m + (pi / pcols) * 2, rx = m + (pi % pcols) * 4;
-        float s_inv[8];
-        bool border[8];
+    constexpr int NTHR = 512 / PH;
+    const int pcols = (rw + 3) >> 2, prows = (rh + PH - 1) / PH;
+    for (int pi = threadIdx.x; pi < pcols * prows; pi += NTHR) {
+        const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
+        float s_inv[4 * PH];
+        bool border[4 * PH];
 #pragma unroll
-        for (int py = 0; py < 2; py++)
+        for (int py = 0; py < PH; py++)
 #pragma unroll
             for (int px = 0; px < 4; px++) {
                 int gy = tc.iy0 + ry + py, gx = tc.ix0 + rx + px;
@@ -198,10 +200,10 @@ __device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* 
                 gx = min(max(gx, 0), tc.W - 1);
                 s_inv[py * 4 + px] = sig[((gy >> 3) - scy0) * 16 + ((gx >> 3) - scx0)];
             }
-        float res[3][8];
-        epf_patch<ITER, SW, PLANE>(src, ry, rx, s_inv, border, ep, res);
+        float res[3][4 * PH];
+        epf_patch<ITER, SW, PLANE, PH>(src, ry, rx, s_inv, border, ep, res);
 #pragma unroll
-        for (int py = 0; py < 2; py++)
+        for (int py = 0; py < PH; py++)
 #pragma unroll
             for (int px = 0; px < 4; px++) {
                 const int y = ry + py, x = rx + px;
@@ -218,11 +220,11 @@ __device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* 
 
 // after a non-final stage on an edge tile: positions of the region outside the frame take the value of
 // their mirrored in-frame position (what a mirrored read of the full-frame plane would return)
-template <typename G>
+template <typename G, int NTHR>
 __device__ __forceinline__ void mirror_fixup(float* __restrict__ buf, int m, int rem, const TileCtx& tc) {
     const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
     __syncthreads();
-    for (int i = threadIdx.x; i < rw * rh; i += 256) {
+    for (int i = threadIdx.x; i < rw * rh; i += NTHR) {
         const int y = m + i / rw, x = m + i % rw;
         const int gy = tc.iy0 + y, gx = tc.ix0 + x;
         const bool outside = gy < 0 || gy >= tc.H || gx < 0 || gx >= tc.W;
@@ -245,9 +247,12 @@ struct FusedArgs {
     RestoreParams p;
 };
 
-template <bool GAB, int ITERS>
-__global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
+// PLAIN = true: float planes out, no transfer function (keeps the double-precision pow() code of the
+// PQ/sRGB transfer out of the hot variant)
+template <bool GAB, int ITERS, bool PLAIN, int PH>
+__global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(const FusedArgs a) {
     using G = Geo<GAB, ITERS>;
+    constexpr int NTHR = 512 / PH;
     extern __shared__ float lds[];
     float* A = lds;
     float* B = lds + 3 * G::PLANE;
@@ -264,17 +269,17 @@ __global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
     // inverse sigma per cell (Frame.java:552-571)
     const int scy0 = max(tc.iy0, 0) >> 3, scx0 = max(tc.ix0, 0) >> 3;
     if (ITERS > 0) {
-        const int cy = scy0 + (threadIdx.x >> 4), cx = scx0 + (threadIdx.x & 15);
+        const int cy = scy0 + ((threadIdx.x & 255) >> 4), cx = scx0 + (threadIdx.x & 15);
         float v = 0.0f;
         if (cy < ((H + 7) >> 3) && cx < a.bw) {
             const int sharp = a.sharpness[cy * a.bw + cx] & 7;
             const float sigma = a.p.global_scale_f * a.p.sharp_lut[sharp] / (float)a.hf_mul[cy * a.bw + cx];
             v = 1.0f / sigma;
         }
-        sig[threadIdx.x] = v;
+        sig[threadIdx.x & 255] = v;
     }
     // load the input tile: clamped coordinates feed Gab, mirrored ones feed EPF directly
-    for (int i = threadIdx.x; i < G::IW * G::IH; i += 256) {
+    for (int i = threadIdx.x; i < G::IW * G::IH; i += NTHR) {
         const int y = i / G::IW, x = i % G::IW;
         int gy = tc.iy0 + y, gx = tc.ix0 + x;
         if (tc.edge) {
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
     if (GAB) {  // Frame.performGabConvolution (:505-542)
         m = 1;
         const int rw = G::IW - 2, rh = G::IH - 2;
-        for (int i = threadIdx.x; i < rw * rh; i += 256) {
+        for (int i = threadIdx.x; i < rw * rh; i += NTHR) {
             const int y = 1 + i / rw, x = 1 + i % rw;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
                 oth[c * G::PLANE + y * G::SW + x] = a.p.gab_base[c] * p[0] + a.p.gab_adj[c] * adj + a.p.gab_diag[c] * diag;
             }
         }
-        if (tc.edge && ITERS > 0) mirror_fixup<G>(oth, m, G::RE, tc);
+        if (tc.edge && ITERS > 0) mirror_fixup<G, NTHR>(oth, m, G::RE, tc);
         __syncthreads();
         float* t = cur; cur = oth; oth = t;
     }
@@ -330,6 +335,11 @@ __global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
         }
         const int64_t g = (int64_t)gy * W + gx;
         float v[3] = {v0, v1, v2};
+        if (PLAIN) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             float t = v[c];
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
 
     if (ITERS == 0) {
         const int mm = m;
-        for (int i = threadIdx.x; i < G::OW * G::OH; i += 256) {
+        for (int i = threadIdx.x; i < G::OW * G::OH; i += NTHR) {
             const int y = mm + i / G::OW, x = mm + i % G::OW;
             sink(y, x, cur[y * G::SW + x], cur[G::PLANE + y * G::SW + x], cur[2 * G::PLANE + y * G::SW + x]);
         }
@@ -357,35 +367,44 @@ __global__ __launch_bounds__(256, 2) void k_restore_fused(const FusedArgs a) {
     }
     if (ITERS == 3) {
         m += 3;
-        epf_stage<0, G, false>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
-        if (tc.edge) mirror_fixup<G>(oth, m, G::R1 + G::R2, tc);
+        epf_stage<0, G, false, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
+        if (tc.edge) mirror_fixup<G, NTHR>(oth, m, G::R1 + G::R2, tc);
         __syncthreads();
         float* t = cur; cur = oth; oth = t;
     }
     m += 2;
     if (ITERS >= 2) {
-        epf_stage<1, G, false>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
-        if (tc.edge) mirror_fixup<G>(oth, m, G::R2, tc);
+        epf_stage<1, G, false, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
+        if (tc.edge) mirror_fixup<G, NTHR>(oth, m, G::R2, tc);
         __syncthreads();
         float* t = cur; cur = oth; oth = t;
         m += 1;
-        epf_stage<2, G, true>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[2], sink);
+        epf_stage<2, G, true, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[2], sink);
     } else {
-        epf_stage<1, G, true>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
+        epf_stage<1, G, true, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
     }
 }
 
-template <bool GAB, int ITERS>
-void launch_t(const FusedArgs& a, hipStream_t s) {
+template <bool GAB, int ITERS, bool PLAIN>
+void launch_tp(const FusedArgs& a, hipStream_t s) {
     using G = Geo<GAB, ITERS>;
+    // iteration 0 (13 taps) keeps the 4x2 patch / 256 threads; the common configurations run 4x1 patches on
+    // 512 threads: twice the waves per CU for the same LDS footprint
+    constexpr int PH = ITERS == 3 ? 2 : 1;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused<GAB, ITERS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused<GAB, ITERS, PLAIN, PH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         attr_set = true;
     }
     const dim3 grid((a.W + G::OW - 1) / G::OW, (a.H + G::OH - 1) / G::OH);
-    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS>), grid, dim3(256), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES, s, a);
+}
+
+template <bool GAB, int ITERS>
+void launch_t(const FusedArgs& a, hipStream_t s) {
+    if (a.p.transfer == JXL_TRANSFER_NONE && a.p.max_value == 0) launch_tp<GAB, ITERS, true>(a, s);
+    else launch_tp<GAB, ITERS, false>(a, s);
 }
 
 }  // namespace
