@@ -68,7 +68,7 @@ struct jxl_ctx {
     bool have_weights = false;
     jxl_vardct_params p{};
     int W = 0, H = 0, bw = 0, bh = 0, tw = 0, th = 0;
-    DevBuf coeff[3], lf[3], hf_mul, sharp, xfy, bfy, weights, planeA[3], planeB[3], outbuf[3], inv_sigma, blocks, items,
+    DevBuf coeff[3], lf[3], llf[3], weights_t, hf_mul, sharp, xfy, bfy, weights, planeA[3], planeB[3], outbuf[3], inv_sigma, blocks, items,
         group_tmp, bad_flag;
     int32_t woffs[51]{};
     std::vector<int32_t> h_hf_mul, h_sharp, h_xfy, h_bfy;
@@ -77,10 +77,11 @@ struct jxl_ctx {
     std::vector<std::vector<DevBlock>> lfg_blocks;  // per LF group, reference order, frame coordinates
     std::vector<uint8_t> lfg_set;
     // binned work
-    int n_small_items = 0, small_items_off = 0;
-    struct MedLaunch { int type, items_off, n_items; };
-    std::vector<MedLaunch> med;
+    struct TypeLaunch { int type, items_off, n_items; };
+    std::vector<TypeLaunch> type_launches;
+    int special_off = 0, n_special_items = 0;
     int large_first = 0, large_count = 0;
+    int llf_first = 0, llf_count = 0;  // blocks larger than 8x8 (contiguous in h_blocks)
     std::vector<DevBlock> h_blocks;
     // results
     void* result[3] = {nullptr, nullptr, nullptr};
@@ -91,6 +92,11 @@ struct jxl_ctx {
     hipEvent_t ev[kEvSlots][3] = {};  // ring of (start, after IDCT stage, end) per run
     int ev_runs = 0;                  // runs recorded since timing was enabled
     bool owns_stream = true;
+    // fork/join side streams: the per-type IDCT kernels are independent and individually too small to fill
+    // 256 CUs, so they run concurrently
+    static constexpr int kAux = 4;
+    hipStream_t aux[kAux] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[kAux] = {};
 
     // ---- Modular state
     std::vector<DevBuf> mod_bufs;
@@ -192,34 +198,48 @@ jxl_status finalize_tables(jxl_ctx* c) {
             sm[b.type].push_back(b);
         }
     }
-    // layout: [small types..., medium types..., large types...]
+    // layout: [8x8-footprint types..., medium types..., large types...]; expensive items first so that the
+    // tail of the single launch is made of cheap workgroups
     c->h_blocks.clear();
     std::vector<WorkItem> items;
-    c->med.clear();
-    c->small_items_off = 0;
-    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
-        if (!is_small(t) || sm[t].empty()) continue;
-        const uint32_t first = (uint32_t)c->h_blocks.size();
-        c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
+    c->llf_first = -1;
+    std::vector<uint32_t> first_of(JXL_NUM_TRANSFORM_TYPES, 0);
+    for (int pass = 0; pass < 2; pass++)
+        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
+            if (is_large(t) || sm[t].empty() || is_small(t) != (pass == 0)) continue;
+            if (pass == 1 && c->llf_first < 0) c->llf_first = (int)c->h_blocks.size();
+            first_of[t] = (uint32_t)c->h_blocks.size();
+            c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
+        }
+    static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};
+    c->type_launches.clear();
+    for (int t : kOrder) {
+        if (sm[t].empty()) continue;
+        jxl_ctx::TypeLaunch tl{t, (int)items.size(), 0};
+        if (t == 0) {
+            for (uint32_t o = 0; o < sm[t].size(); o += 64)
+                items.push_back(WorkItem{(uint32_t)t, first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
+        } else {
+            const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
+            for (uint32_t o = 0; o < sm[t].size(); o += nb)
+                for (uint32_t ch = 0; ch < 3; ch++)
+                    items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(nb, sm[t].size() - o)});
+        }
+        tl.n_items = (int)items.size() - tl.items_off;
+        c->type_launches.push_back(tl);
+    }
+    c->special_off = (int)items.size();
+    static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
+    for (int t : kSpecial)
         for (uint32_t o = 0; o < sm[t].size(); o += 64)
-            items.push_back(WorkItem{(uint32_t)t, first + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
-    }
-    c->n_small_items = (int)items.size();
-    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
-        if (is_small(t) || is_large(t) || sm[t].empty()) continue;
-        const uint32_t first = (uint32_t)c->h_blocks.size();
-        c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
-        const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
-        jxl_ctx::MedLaunch ml{t, (int)items.size(), 0};
-        for (uint32_t o = 0; o < sm[t].size(); o += nb)
-            items.push_back(WorkItem{(uint32_t)t, first + o, (uint32_t)std::min<size_t>(nb, sm[t].size() - o)});
-        ml.n_items = (int)items.size() - ml.items_off;
-        c->med.push_back(ml);
-    }
+            items.push_back(WorkItem{(uint32_t)t, first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
+    c->n_special_items = (int)items.size() - c->special_off;
     c->large_first = (int)c->h_blocks.size();
     for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
         if (is_large(t)) c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
     c->large_count = (int)c->h_blocks.size() - c->large_first;
+    c->llf_first = c->large_first;  // only the 128/256-edge blocks take their LLF from the llf planes (k_llf)
+    c->llf_count = c->large_count;
 
     if (!c->blocks.ensure(sizeof(DevBlock) * std::max<size_t>(1, c->h_blocks.size())) ||
         !c->items.ensure(sizeof(WorkItem) * std::max<size_t>(1, items.size())))
@@ -233,8 +253,11 @@ jxl_status finalize_tables(jxl_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->sharp.p, c->h_sharp.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->xfy.p, c->h_xfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->bfy.p, c->h_bfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
-    for (int ch = 0; ch < 3; ch++)
+    for (int ch = 0; ch < 3; ch++) {
         HIP_TRY(c, hipMemcpyAsync(c->lf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+        // llf starts as a copy of lf (the LLF of an 8x8 block is its LF sample); k_llf overwrites the cells of larger blocks
+        HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
     c->tables_dirty = false;
     return JXL_OK;
@@ -245,6 +268,7 @@ void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
     for (int ch = 0; ch < 3; ch++) {
         f.coeff[ch] = c->coeff[ch].as<int32_t>();
         f.lf[ch] = c->lf[ch].as<float>();
+        f.llf[ch] = c->llf[ch].as<float>();
         f.scale_factor[ch] = c->p.scale_factor[ch];
         f.quant_bias[ch] = c->p.quant_bias[ch];
     }
@@ -253,6 +277,7 @@ void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
     f.x_from_y = c->xfy.as<int32_t>();
     f.b_from_y = c->bfy.as<int32_t>();
     f.weights = c->weights.as<float>();
+    f.weights_t = c->weights_t.as<float>();
     memcpy(f.woffs, c->woffs, sizeof f.woffs);
     f.lut = c->lut.as<float>();
     f.quant_bias_numerator = c->p.quant_bias_numerator;
@@ -339,6 +364,11 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     }
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
+    (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
+    for (int i = 0; i < jxl_ctx::kAux; i++) {
+        (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming);
+    }
     *out = c;
     return JXL_OK;
 }
@@ -347,16 +377,21 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf* all[] = {&c->lut, &c->hf_mul, &c->sharp, &c->xfy, &c->bfy, &c->weights, &c->inv_sigma, &c->blocks, &c->items,
+    DevBuf* all[] = {&c->lut, &c->hf_mul, &c->sharp, &c->xfy, &c->bfy, &c->weights, &c->weights_t, &c->inv_sigma, &c->blocks, &c->items,
                      &c->group_tmp, &c->bad_flag};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 3; i++) {
-        c->coeff[i].release(); c->lf[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
+        c->coeff[i].release(); c->lf[i].release(); c->llf[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
     }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    for (int i = 0; i < jxl_ctx::kAux; i++) {
+        if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
+        if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]);
+    }
     if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -398,7 +433,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     bool ok = true;
     for (int i = 0; i < 3; i++) {
         ok = ok && c->coeff[i].ensure(4 * npx) && c->planeA[i].ensure(4 * npx) && c->planeB[i].ensure(4 * npx) &&
-             c->lf[i].ensure(4 * nc);
+             c->lf[i].ensure(4 * nc) && c->llf[i].ensure(4 * nc);
         if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
     }
     ok = ok && c->hf_mul.ensure(4 * nc) && c->sharp.ensure(4 * nc) && c->xfy.ensure(4 * nt) && c->bfy.ensure(4 * nt) &&
@@ -437,8 +472,24 @@ jxl_status jxl_vardct_set_weights(jxl_ctx* c, const float* w, size_t n_floats, c
             if (o < 0 || (size_t)o + (size_t)mh * mw > n_floats) return fail(c, JXL_ERR_INVALID_ARGUMENT, "weight offset %d out of range", o);
         }
     }
-    if (!c->weights.ensure(sizeof(float) * n_floats)) return fail(c, JXL_ERR_OOM, "device allocation failed (weights)");
+    if (!c->weights.ensure(sizeof(float) * n_floats) || !c->weights_t.ensure(sizeof(float) * n_floats))
+        return fail(c, JXL_ERR_OOM, "device allocation failed (weights)");
     HIP_TRY(c, hipMemcpy(c->weights.p, w, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+    {   // transposed copy of every matrix: flip() blocks index w3[x][y] (HFCoefficients.java:312-314)
+        std::vector<float> wt(w, w + n_floats);
+        for (int pi = 0; pi < JXL_NUM_WEIGHT_SETS; pi++) {
+            int mh = 0, mw = 0;
+            for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+                if (JXL_TT[t].param_index == pi && !(JXL_TT[t].ph > JXL_TT[t].pw)) { mh = jxl_tt_mh(&JXL_TT[t]); mw = jxl_tt_mw(&JXL_TT[t]); break; }
+            for (int ch = 0; ch < 3; ch++) {
+                const float* src = w + offs[pi * 3 + ch];
+                float* dst = wt.data() + offs[pi * 3 + ch];
+                for (int y = 0; y < mh; y++)
+                    for (int x = 0; x < mw; x++) dst[(size_t)x * mh + y] = src[(size_t)y * mw + x];
+            }
+        }
+        HIP_TRY(c, hipMemcpy(c->weights_t.p, wt.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice));
+    }
     memcpy(c->woffs, offs, sizeof c->woffs);
     c->have_weights = true;
     return JXL_OK;
@@ -536,14 +587,35 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         fill_dev_frame(c, f);
         const DevBlock* blocks = c->blocks.as<DevBlock>();
         const WorkItem* items = c->items.as<WorkItem>();
-        if (c->n_small_items > 0) {
-            launch_idct_small(f, blocks, items + c->small_items_off, c->n_small_items, A, s);
+        if (c->llf_count > 0) {
+            float* L[3] = {c->llf[0].as<float>(), c->llf[1].as<float>(), c->llf[2].as<float>()};
+            launch_llf(f, blocks, c->llf_first, c->llf_count, L, s);
             launches++;
         }
-        for (const auto& ml : c->med) {
-            launch_idct_medium_type(f, blocks, items + ml.items_off, ml.n_items, ml.type, A, s);
+        // fork: every type kernel writes a disjoint set of varblocks
+        const int n_k = (int)c->type_launches.size() + (c->n_special_items > 0 ? 1 : 0);
+        const bool fork = n_k > 1;
+        int used = 0;
+        if (fork) {
+            (void)hipEventRecord(c->fork_ev, s);
+            used = std::min(n_k - 1, (int)jxl_ctx::kAux);
+            for (int i = 0; i < used; i++) (void)hipStreamWaitEvent(c->aux[i], c->fork_ev, 0);
+        }
+        int k = 0;
+        auto pick = [&]() { const int i = k++; return (!fork || i % (used + 1) == 0) ? s : c->aux[i % (used + 1) - 1]; };
+        for (const auto& tl : c->type_launches) {
+            launch_idct_type(f, blocks, items + tl.items_off, tl.n_items, tl.type, A, pick());
             launches++;
         }
+        if (c->n_special_items > 0) {
+            launch_idct_special(f, blocks, items + c->special_off, c->n_special_items, A, pick());
+            launches++;
+        }
+        if (fork)
+            for (int i = 0; i < used; i++) {
+                (void)hipEventRecord(c->join_ev[i], c->aux[i]);
+                (void)hipStreamWaitEvent(s, c->join_ev[i], 0);
+            }
         if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
     }
     if (c->timing) (void)hipEventRecord(evs[1], s);

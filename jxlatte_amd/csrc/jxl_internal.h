@@ -36,11 +36,13 @@ struct DevFrame {
     int32_t tw, th;         // 64x64 tiles
     const int32_t* coeff[3];
     const float* lf[3];     // [bh][bw]
+    const float* llf[3];    // [bh][bw]: lf with the LLF coefficients of blocks larger than 8x8 (k_llf)
     const int32_t* hf_mul;  // [bh][bw]
     const int32_t* sharpness;
     const int32_t* x_from_y;  // [th][tw]
     const int32_t* b_from_y;
     const float* weights;     // flat, reciprocal
+    const float* weights_t;   // same offsets, every matrix transposed (for flip() blocks: coalesced reads)
     int32_t woffs[51];
     const float* lut;         // cosine LUT, all sizes; size s=1<<l starts at lut_off(l)
     float scale_factor[3];
@@ -71,12 +73,17 @@ struct XybParams {
 };
 
 // ---- launchers (defined in the kernel TUs) ---------------------------------------------------
-void launch_idct_small(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items,
-                       float* const out[3], hipStream_t s);
-// items of ONE medium type (DCT16..DCT64 and rectangles); count <= medium_blocks_per_wg(type) per item
-void launch_idct_medium_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items_dev, int n_items, int type,
-                             float* const out[3], hipStream_t s);
+// One launch per transform type present (own register budget per type). WorkItem.type = TransformType.type |
+// channel << 8: medium items cover medium_blocks_per_wg(type) blocks of one channel (one wave); DCT8 items
+// cover up to 64 blocks, all channels.
+void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, int type, float* const out[3],
+                      hipStream_t s);
+// the special 8x8-footprint types: items of up to 64 blocks (one per lane)
+void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],
+                         hipStream_t s);
 int medium_blocks_per_wg(int type);
+// finalizeLLF of blocks[first..first+count) (all larger than 8x8) into the llf planes
+void launch_llf(const DevFrame& f, const DevBlock* blocks, int first, int count, float* const llf[3], hipStream_t s);
 // large (128/256-edge) blocks: `first..first+count` of `blocks`; scratch planes same shape as out
 void launch_idct_large(const DevFrame& f, const DevBlock* blocks, const DevBlock* host_blocks, int first, int count,
                        float* const out[3], float* const scratch[3], hipStream_t s, int* n_launches);

@@ -235,12 +235,50 @@ __device__ __forceinline__ void cfl_factors(const DevFrame& f, int ty, int tx, b
     }
 }
 
-// ---- small: one lane = one 8x8 varblock, 3 channels -----------------------------------------------
-template <int TYPE>
-__device__ __forceinline__ void small_block(const DevFrame& f, const DevBlock b, float* __restrict__ o0,
-                                            float* __restrict__ o1, float* __restrict__ o2) {
-    constexpr int PI = TYPE == 0 ? 0 : TYPE == 1 ? 1 : TYPE == 2 ? 2 : TYPE == 3 ? 3 : (TYPE == 12 || TYPE == 13) ? 9 : 10;
-    constexpr bool FLIP = TYPE == 0;  // TransformType.flip(): square METHOD_DCT
+// ---- small: one lane = one 8x8 varblock -------------------------------------------------------------
+// dequantised coefficient row `y` of channel c of an 8x8-footprint block: co[x], x = 0..7, with
+// chroma-from-luma applied (the luma row is dequantised again for each chroma channel instead of being
+// kept in 64 registers) and the LLF sample inserted at (0,0).
+template <int PI, bool FLIP>
+__device__ __forceinline__ void small_row(const DevFrame& f, int c, int y, int64_t base, float hfm, float kc, float lf_c,
+                                          float co[8]) {
+    const int W = f.width;
+    const float qbn = f.quant_bias_numerator;
+    auto load8 = [&](int ch, int q[8]) {
+        const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + base + (int64_t)y * W);
+        const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + base + (int64_t)y * W + 4);
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    };
+    int q[8];
+    load8(c, q);
+    const float* w = f.weights + f.woffs[PI * 3 + c];
+    const float sfc = f.scale_factor[c] / hfm;
+    const float qb = f.quant_bias[c];
+#pragma unroll
+    for (int x = 0; x < 8; x++) co[x] = dequant1(q[x], qb, qbn, sfc, w[FLIP ? x * 8 + y : y * 8 + x]);
+    if (c != 1) {
+        int qy[8];
+        load8(1, qy);
+        const float* wy = f.weights + f.woffs[PI * 3 + 1];
+        const float sfy = f.scale_factor[1] / hfm;
+        const float qby = f.quant_bias[1];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            float dy = dequant1(qy[x], qby, qbn, sfy, wy[FLIP ? x * 8 + y : y * 8 + x]);
+            if (y == 0 && x == 0) dy = 0.0f;  // the LLF corner is skipped by the dequantiser (:305-306)
+            co[x] = co[x] + kc * dy;          // chromaFromLuma (:186-188)
+        }
+    }
+    // finalizeLLF for a 1x1 dctSelect: forwardDCT2D of one sample is sample * (1f/1) twice and llfScale is
+    // 1f*1f: multiplications by exactly 1.0f, i.e. the LF sample itself
+    if (y == 0) co[0] = lf_c;
+}
+
+// DCT8: rows are streamed through the column pass (its sum runs over n = row index in ascending order, the
+// reference's order), so only the 64 column accumulators stay live; the row pass emits one output row at a
+// time. ~100 VGPRs instead of 350.
+__device__ __forceinline__ void dct8_block(const DevFrame& f, const DevBlock b, float* __restrict__ o0, float* __restrict__ o1,
+                                           float* __restrict__ o2) {
     const int W = f.width;
     const int py0 = b.cy * 8, px0 = b.cx * 8;
     const int64_t base = (int64_t)py0 * W + px0;
@@ -248,51 +286,54 @@ __device__ __forceinline__ void small_block(const DevFrame& f, const DevBlock b,
     float kX, kB;
     cfl_factors(f, py0 >> 6, px0 >> 6, b.cfl_zero & 1u, kX, kB);
     float* outs[3] = {o0, o1, o2};
-
-    float dqY[64];
-    {
-        const float* w = f.weights + f.woffs[PI * 3 + 1];
-        const float sfc = f.scale_factor[1] / hfm;
-        const float qb = f.quant_bias[1];
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const float kc = c == 0 ? kX : kB;
+        const float lf_c = f.lf[c][b.cy * f.bw + b.cx];
+        float t[64];  // t[k*8 + x]: column pass result
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-            const int4 a = *reinterpret_cast<const int4*>(f.coeff[1] + base + (int64_t)y * W);
-            const int4 c = *reinterpret_cast<const int4*>(f.coeff[1] + base + (int64_t)y * W + 4);
-            const int q[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        for (int n = 0; n < 8; n++) {
+            float co[8];
+            small_row<0, true>(f, c, n, base, hfm, kc, lf_c, co);
 #pragma unroll
-            for (int x = 0; x < 8; x++)
-                dqY[y * 8 + x] = dequant1(q[x], qb, f.quant_bias_numerator, sfc, w[FLIP ? x * 8 + y : y * 8 + x]);
-        }
-        dqY[0] = 0.0f;  // LLF corner is skipped by the dequantiser (:305-306); CfL reads 0 there
-    }
+            for (int x = 0; x < 8; x++) {
 #pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-        const int c = ci == 0 ? 0 : ci == 1 ? 2 : 1;  // X, B, then Y
-        float co[64];
-        if (c == 1) {
-#pragma unroll
-            for (int i = 0; i < 64; i++) co[i] = dqY[i];
-        } else {
-            const float* w = f.weights + f.woffs[PI * 3 + c];
-            const float sfc = f.scale_factor[c] / hfm;
-            const float qb = f.quant_bias[c];
-            const float k = c == 0 ? kX : kB;
-#pragma unroll
-            for (int y = 0; y < 8; y++) {
-                const int4 a = *reinterpret_cast<const int4*>(f.coeff[c] + base + (int64_t)y * W);
-                const int4 d = *reinterpret_cast<const int4*>(f.coeff[c] + base + (int64_t)y * W + 4);
-                const int q[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-                for (int x = 0; x < 8; x++) {
-                    const float v = dequant1(q[x], qb, f.quant_bias_numerator, sfc, w[FLIP ? x * 8 + y : y * 8 + x]);
-                    co[y * 8 + x] = v + k * dqY[y * 8 + x];  // chromaFromLuma (:186-188)
+                for (int k = 0; k < 8; k++) {
+                    if (n == 0) t[k * 8 + x] = co[x];
+                    else t[k * 8 + x] = t[k * 8 + x] + co[x] * kLut8[n - 1][k];
                 }
             }
         }
-        // finalizeLLF for a 1x1 dctSelect: forwardDCT2D of one sample is sample * (1f/1) twice, llfScale = 1f*1f:
-        // multiplications by exactly 1.0f, i.e. the LF sample itself
-        co[0] = f.lf[c][b.cy * f.bw + b.cx];
-        float px[64];
+        float* o = outs[c] + base;
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            float r[8];
+            idct1d_reg<8, 1, 1>(t + y * 8, r);
+            *reinterpret_cast<float4*>(o + (int64_t)y * W) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(o + (int64_t)y * W + 4) = make_float4(r[4], r[5], r[6], r[7]);
+        }
+    }
+}
+
+// the other nine 8x8-footprint types: whole block of one channel in registers
+template <int TYPE>
+__device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock b, float* __restrict__ o0,
+                                              float* __restrict__ o1, float* __restrict__ o2) {
+    constexpr int PI = TYPE == 1 ? 1 : TYPE == 2 ? 2 : TYPE == 3 ? 3 : (TYPE == 12 || TYPE == 13) ? 9 : 10;
+    const int W = f.width;
+    const int py0 = b.cy * 8, px0 = b.cx * 8;
+    const int64_t base = (int64_t)py0 * W + px0;
+    const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+    float kX, kB;
+    cfl_factors(f, py0 >> 6, px0 >> 6, b.cfl_zero & 1u, kX, kB);
+    float* outs[3] = {o0, o1, o2};
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const float kc = c == 0 ? kX : kB;
+        const float lf_c = f.lf[c][b.cy * f.bw + b.cx];
+        float co[64], px[64];
+#pragma unroll
+        for (int y = 0; y < 8; y++) small_row<PI, false>(f, c, y, base, hfm, kc, lf_c, co + y * 8);
         invert_small<TYPE>(co, px);
         float* o = outs[c] + base;
 #pragma unroll
@@ -302,32 +343,6 @@ __device__ __forceinline__ void small_block(const DevFrame& f, const DevBlock b,
                 make_float4(px[y * 8 + 4], px[y * 8 + 5], px[y * 8 + 6], px[y * 8 + 7]);
         }
     }
-}
-
-__global__ __launch_bounds__(64) void k_idct_small(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                   const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
-    const WorkItem it = items[blockIdx.x];
-    if (threadIdx.x >= it.count) return;
-    const DevBlock b = blocks[it.first + threadIdx.x];
-    switch (it.type) {
-    case 0: small_block<0>(f, b, o0, o1, o2); break;
-    case 1: small_block<1>(f, b, o0, o1, o2); break;
-    case 2: small_block<2>(f, b, o0, o1, o2); break;
-    case 3: small_block<3>(f, b, o0, o1, o2); break;
-    case 12: small_block<12>(f, b, o0, o1, o2); break;
-    case 13: small_block<13>(f, b, o0, o1, o2); break;
-    case 14: small_block<14>(f, b, o0, o1, o2); break;
-    case 15: small_block<15>(f, b, o0, o1, o2); break;
-    case 16: small_block<16>(f, b, o0, o1, o2); break;
-    case 17: small_block<17>(f, b, o0, o1, o2); break;
-    default: break;
-    }
-}
-
-void launch_idct_small(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items,
-                       float* const out[3], hipStream_t s) {
-    if (n_items <= 0) return;
-    hipLaunchKernelGGL(k_idct_small, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
 }
 
 // ---- shared pieces of medium / large ---------------------------------------------------------------
@@ -389,6 +404,22 @@ __device__ __forceinline__ void dequant_sample(const DevFrame& f, const BlockCtx
     dq[2] = db + kB * dy;
 }
 
+// one channel of dequant_sample (luma is dequantised again for the chroma channels)
+__device__ __forceinline__ float dequant_sample_c(const DevFrame& f, const BlockCtx& k, int c, int y, int x) {
+    if (y < k.dsh && x < k.dsw) return 0.0f;
+    const int64_t off = (int64_t)(k.py0 + y) * f.width + k.px0 + x;
+    const int wy = k.flip ? x : y, wx = k.flip ? y : x;
+    const int wi = wy * k.mw + wx;
+    const float dy = dequant1(f.coeff[1][off], f.quant_bias[1], f.quant_bias_numerator, k.sfc[1], k.w[1][wi]);
+    if (c == 1) return dy;
+    const float dc = dequant1(f.coeff[c][off], f.quant_bias[c], f.quant_bias_numerator, k.sfc[c], k.w[c][wi]);
+    const int ty = (k.py0 + y) >> 6, tx = (k.px0 + x) >> 6;
+    const int bit = (ty - k.ty0) * 5 + (tx - k.tx0);
+    float kX, kB;
+    cfl_factors(f, ty, tx, (k.cfl_zero >> bit) & 1u, kX, kB);
+    return dc + (c == 0 ? kX : kB) * dy;
+}
+
 // finalizeLLF (HFCoefficients.java:194-229) for one block and channel, executed by `nthr` threads
 // (thread ids tid = 0..nthr-1) of a workgroup. s0/s1: LDS scratch of dsh*dsw floats each. Writes
 // the dsh x dsw corner through put(k_row, k_col, value). Contains __syncthreads: call uniformly.
@@ -442,150 +473,270 @@ __device__ __forceinline__ void llf_block(const DevFrame& f, int cy, int cx, int
     __syncthreads();
 }
 
-// ---- medium: DCT16..DCT64 and rectangles, LDS resident ----------------------------------------------
+// One LLF coefficient (ky, kx) of a DSH x DSW LF patch: forwardDCT2D (MathHelper.java:124-136) row pass for
+// column kx of every row, then the column pass for ky, times llfScale (HFCoefficients.java:194-229). Each lane
+// recomputes the row-pass values it needs; the values are deterministic, so this equals the reference's
+// shared scratch arrays bit for bit.
+template <int DSH, int DSW>
+__device__ __forceinline__ float llf_coeff(const DevFrame& f, const float* __restrict__ lfp /* patch origin, stride f.bw */, int ky,
+                                           int kx) {
+    const float* lutw = f.lut + lut_off(ceil_log2_dev(DSW));
+    const float* luth = f.lut + lut_off(ceil_log2_dev(DSH));
+    const float invw = 1.0f / (float)DSW, invh = 1.0f / (float)DSH;
+    float r[DSH];
+#pragma unroll
+    for (int y = 0; y < DSH; y++) {
+        const float* row = lfp + (int64_t)y * f.bw;
+        float d2;
+        if (kx == 0) {
+            d2 = row[0];
+#pragma unroll
+            for (int x = 1; x < DSW; ++x) d2 = d2 + row[x];
+        } else {
+            const float* lut = lutw + (kx - 1) * DSW;
+            d2 = row[0] * lut[0];
+#pragma unroll
+            for (int n = 1; n < DSW; ++n) d2 = d2 + row[n] * lut[n];
+        }
+        r[y] = d2 * invw;
+    }
+    float d2;
+    if (ky == 0) {
+        d2 = r[0];
+#pragma unroll
+        for (int y = 1; y < DSH; ++y) d2 = d2 + r[y];
+    } else {
+        const float* lut = luth + (ky - 1) * DSH;
+        d2 = r[0] * lut[0];
+#pragma unroll
+        for (int n = 1; n < DSH; ++n) d2 = d2 + r[n] * lut[n];
+    }
+    constexpr int yll = DSH <= 1 ? 0 : DSH <= 2 ? 1 : DSH <= 4 ? 2 : 3;
+    constexpr int xll = DSW <= 1 ? 0 : DSW <= 2 ? 1 : DSW <= 4 ? 2 : 3;
+    return (d2 * invh) * (kLlfScale[ky << (5 - yll)] * kLlfScale[kx << (5 - xll)]);
+}
+
+// ---- medium: DCT16..DCT64 and rectangles: one WAVE = BPW blocks of ONE channel, no workgroup barriers ----
+// Column pass: lane = one column of a block; the coefficient rows are streamed from global memory in row
+// order n = 0,1,.. (dequantised on the fly), which is exactly the order of the reference's sum, so the H
+// partial sums of the column live in VGPRs and every LUT row is wave-uniform (scalar loads). The column
+// results are transposed through a wave-private LDS image (stride W+1, conflict-free both ways); row pass:
+// lane = one row, W partial sums in VGPRs, the finished row leaves as 16-byte stores.
 template <int H, int W>
 struct MediumCfg {
     static constexpr int MAXD = H > W ? H : W;
-    static constexpr int NB = (256 / (3 * MAXD)) > 0 ? (256 / (3 * MAXD)) : 1;  // blocks per workgroup
-    static constexpr int LD = W + 1;                                           // padded row stride
-    static constexpr int BLK_FLOATS = 3 * H * LD;
-    static constexpr int LLF_FLOATS = 2 * (H / 8) * (W / 8);                   // per (block, channel) scratch pair
-    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(NB * BLK_FLOATS + 2 * 64);
+    static constexpr int BPW = 64 / MAXD;  // blocks per wave
+    static constexpr int LD = W + 1;       // padded row stride
+    static constexpr int IMG = H * LD;     // floats per block image
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(BPW * IMG);
 };
 
 template <int H, int W, int TYPE>
-__global__ __launch_bounds__(256) void k_idct_medium(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                     const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+__device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* __restrict__ blocks, const WorkItem it,
+                                            float* __restrict__ lds, float* __restrict__ o0, float* __restrict__ o1,
+                                            float* __restrict__ o2) {
     using Cfg = MediumCfg<H, W>;
-    constexpr int NB = Cfg::NB, LD = Cfg::LD;
+    constexpr int LD = Cfg::LD, IMG = Cfg::IMG;
     constexpr int PI = JXL_TT[TYPE].param_index;
-    extern __shared__ float lds[];
-    float* buf = lds;                           // [NB][3][H][LD]
-    float* llf_s = lds + NB * Cfg::BLK_FLOATS;  // 2 x 64 floats
-    const WorkItem it = items[blockIdx.x];
+    constexpr bool FLIP = H >= W;  // TransformType.flip() for METHOD_DCT
+    constexpr int DSH = H / 8, DSW = W / 8;
     const int nb = (int)it.count;
-    const int tid = threadIdx.x;
+    const int c = (int)(it.type >> 8);  // channel of this item
+    const int lane = threadIdx.x;
     const int FW = f.width;
-    float* outs[3] = {o0, o1, o2};
+    float* out = c == 0 ? o0 : c == 1 ? o1 : o2;
+    const int* qc_plane = f.coeff[c];
+    const int* qy_plane = f.coeff[1];
+    // reciprocal weights, stored so that consecutive x are consecutive addresses for both orientations
+    const float* wc = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + c];
+    const float* wy = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + 1];
+    const float qbn = f.quant_bias_numerator;
 
-    // 1. dequant + CfL -> LDS
-    for (int bi = 0; bi < nb; bi++) {
-        const DevBlock b = blocks[it.first + bi];
-        BlockCtx k;
-        make_block_ctx(f, b, H, W, PI, k);
-        float* bb = buf + bi * Cfg::BLK_FLOATS;
-        for (int i = tid; i < H * W; i += 256) {
-            const int y = i / W, x = i % W;
-            float dq[3];
-            dequant_sample(f, k, y, x, dq);
-            bb[(0 * H + y) * LD + x] = dq[0];
-            bb[(1 * H + y) * LD + x] = dq[1];
-            bb[(2 * H + y) * LD + x] = dq[2];
-        }
-    }
-    __syncthreads();
-    // 2. LLF corner
-    for (int bi = 0; bi < nb; bi++) {
-        const DevBlock b = blocks[it.first + bi];
-        float* bb = buf + bi * Cfg::BLK_FLOATS;
-        for (int c = 0; c < 3; c++) {
-            llf_block(f, b.cy, b.cx, c, H / 8, W / 8, llf_s, llf_s + 64, tid, 256,
-                      [&](int ky, int kx, float v) { bb[(c * H + ky) * LD + kx] = v; });
-        }
-    }
-    __syncthreads();
-    // 3. column pass: lane = (block, channel, column); H accumulators in VGPRs
+    // ---- column pass
     {
-        const float* lut = f.lut + lut_off(ceil_log2_dev(H));
-        if (tid < nb * 3 * W) {
-            const int bi = tid / (3 * W), r = tid % (3 * W), c = r / W, x = r % W;
-            float* col = buf + bi * Cfg::BLK_FLOATS + (c * H) * LD + x;
+        const int bi = lane / W, x = lane % W;
+        if (bi < nb) {
+            const DevBlock b = blocks[it.first + bi];
+            const int py0 = b.cy * 8, px0 = b.cx * 8;
+            const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+            const float sfc = f.scale_factor[c] / hfm, sfy = f.scale_factor[1] / hfm;
+            const float qbc = f.quant_bias[c], qby = f.quant_bias[1];
+            const int ty0 = py0 >> 6, tx0 = px0 >> 6;
+            const int tx = (px0 + x) >> 6;
+            const float* lfp = f.lf[c] + (int64_t)b.cy * f.bw + b.cx;
+            const float* lut = f.lut + lut_off(ceil_log2_dev(H));
+            float kcfl = 0.0f;
             float acc[H];
-            const float s0 = col[0];
+            // rows in chunks of RC: all global loads of a chunk are issued before its arithmetic, so RC (x2-4)
+            // loads per lane are in flight instead of one dependent load per row
+            constexpr int RC = 8;
+#pragma unroll 1
+            for (int n0 = 0; n0 < H; n0 += RC) {
+                int qcv[RC], qyv[RC];
+                float wcv[RC], wyv[RC];
+                const int64_t off0 = (int64_t)(py0 + n0) * FW + px0 + x;
 #pragma unroll
-            for (int k2 = 0; k2 < H; k2++) acc[k2] = s0;
-            for (int n = 1; n < H; n++) {
-                const float s2 = col[n * LD];
-                const float* lr = lut + (n - 1) * H;
+                for (int r = 0; r < RC; r++) {
+                    qcv[r] = qc_plane[off0 + (int64_t)r * FW];
+                    wcv[r] = wc[(n0 + r) * W + x];  // (FLIP ? transposed table : table)[n][x]
+                    if (c != 1) {
+                        qyv[r] = qy_plane[off0 + (int64_t)r * FW];
+                        wyv[r] = wy[(n0 + r) * W + x];
+                    }
+                }
 #pragma unroll
-                for (int k2 = 0; k2 < H; k2++) acc[k2] = acc[k2] + s2 * lr[k2];
+                for (int r = 0; r < RC; r++) {
+                    const int n = n0 + r;
+                    float co;
+                    if (c != 1 && (n == 0 || ((py0 + n) & 63) == 0)) {  // entering a new CfL tile row
+                        const int ty = (py0 + n) >> 6;
+                        float kX, kB;
+                        cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - ty0) * 5 + (tx - tx0))) & 1u, kX, kB);
+                        kcfl = c == 0 ? kX : kB;
+                    }
+                    if (n < DSH && x < DSW) {
+                        co = llf_coeff<DSH, DSW>(f, lfp, n, x);  // finalizeLLF (:194-229)
+                    } else {
+                        co = dequant1(qcv[r], qbc, qbn, sfc, wcv[r]);
+                        if (c != 1) {
+                            const float dy = dequant1(qyv[r], qby, qbn, sfy, wyv[r]);
+                            co = co + kcfl * dy;  // chromaFromLuma (:186-188)
+                        }
+                    }
+                    if (n == 0) {
+#pragma unroll
+                        for (int k = 0; k < H; k++) acc[k] = co;
+                    } else {
+                        const float* lr = lut + (n - 1) * H;
+#pragma unroll
+                        for (int k = 0; k < H; k++) acc[k] = acc[k] + co * lr[k];
+                    }
+                }
             }
+            float* dcol = lds + bi * IMG + x;
 #pragma unroll
-            for (int k2 = 0; k2 < H; k2++) col[k2 * LD] = acc[k2];
+            for (int k = 0; k < H; k++) dcol[k * LD] = acc[k];
         }
     }
-    __syncthreads();
-    // 4. row pass: lane = (block, channel, row); W accumulators
+    __syncthreads();  // one wave per workgroup: orders the LDS image for the row pass
+    // ---- row pass
     {
-        const float* lut = f.lut + lut_off(ceil_log2_dev(W));
-        if (tid < nb * 3 * H) {
-            const int bi = tid / (3 * H), r = tid % (3 * H), c = r / H, y = r % H;
-            float* row = buf + bi * Cfg::BLK_FLOATS + (c * H + y) * LD;
+        const int bi = lane / H, y = lane % H;
+        if (bi < nb) {
+            const DevBlock b = blocks[it.first + bi];
+            const float* row = lds + bi * IMG + y * LD;
+            const float* lut = f.lut + lut_off(ceil_log2_dev(W));
             float acc[W];
             const float s0 = row[0];
 #pragma unroll
-            for (int k2 = 0; k2 < W; k2++) acc[k2] = s0;
+            for (int k = 0; k < W; k++) acc[k] = s0;
+#pragma unroll 8
             for (int n = 1; n < W; n++) {
                 const float s2 = row[n];
                 const float* lr = lut + (n - 1) * W;
 #pragma unroll
-                for (int k2 = 0; k2 < W; k2++) acc[k2] = acc[k2] + s2 * lr[k2];
+                for (int k = 0; k < W; k++) acc[k] = acc[k] + s2 * lr[k];
             }
+            float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8;
 #pragma unroll
-            for (int k2 = 0; k2 < W; k2++) row[k2] = acc[k2];
+            for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(o + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
         }
     }
-    __syncthreads();
-    // 5. coalesced store
-    for (int bi = 0; bi < nb; bi++) {
-        const DevBlock b = blocks[it.first + bi];
-        const float* bb = buf + bi * Cfg::BLK_FLOATS;
-        const int64_t base = (int64_t)(b.cy * 8) * FW + b.cx * 8;
-        for (int i = tid; i < 3 * H * W; i += 256) {
-            const int c = i / (H * W), r = i % (H * W), y = r / W, x = r % W;
-            outs[c][base + (int64_t)y * FW + x] = bb[(c * H + y) * LD + x];
-        }
-    }
+}
+
+// finalizeLLF (HFCoefficients.java:194-229) of every block larger than 8x8, written over the block's own cells
+// of the llf planes (a block covers exactly dctSelectHeight x dctSelectWidth cells). grid = (3, nblocks).
+__global__ __launch_bounds__(256) void k_llf(const DevFrame f, const DevBlock* __restrict__ blocks, int first, float* l0, float* l1,
+                                             float* l2) {
+    __shared__ float s0[1024], s1[1024];
+    const DevBlock b = blocks[first + blockIdx.y];
+    const jxl_tt_info tt = JXL_TT[b.type];
+    const int c = blockIdx.x;
+    float* o = (c == 0 ? l0 : c == 1 ? l1 : l2) + (int64_t)b.cy * f.bw + b.cx;
+    const int bw = f.bw;
+    llf_block(f, b.cy, b.cx, c, tt.ph >> 3, tt.pw >> 3, s0, s1, threadIdx.x, 256, [&](int ky, int kx, float v) { o[ky * bw + kx] = v; });
+}
+
+void launch_llf(const DevFrame& f, const DevBlock* blocks, int first, int count, float* const llf[3], hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_llf, dim3(3, count), dim3(256), 0, s, f, blocks, first, llf[0], llf[1], llf[2]);
+}
+
+// ---- launches: one kernel per transform type present, each with its own register budget -------------------
+// (a single merged kernel would be allocated the registers of its most demanding branch -- the 64-point
+// accumulators -- and leave the common small types at 2 waves/SIMD; these kernels are latency-sensitive)
+__global__ __launch_bounds__(64) void k_idct_dct8(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                  const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    const WorkItem it = items[blockIdx.x];
+    if (threadIdx.x < it.count) dct8_block(f, blocks[it.first + threadIdx.x], o0, o1, o2);
+}
+
+template <int H, int W, int TYPE>
+__global__ __launch_bounds__(64) void k_idct_medium(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                    const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    extern __shared__ float lds[];
+    medium_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
 }
 
 template <int H, int W, int TYPE>
 static void launch_medium_t(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n, float* const out[3],
                             hipStream_t s) {
-    using Cfg = MediumCfg<H, W>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_medium<H, W, TYPE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        attr_set = true;
+    constexpr size_t lds_bytes = MediumCfg<H, W>::LDS_BYTES;
+    hipLaunchKernelGGL((k_idct_medium<H, W, TYPE>), dim3(n), dim3(64), lds_bytes, s, f, blocks, items, out[0], out[1], out[2]);
+}
+
+// items: all of ONE type. type 0: up to 64 DCT8 blocks per item (all channels); medium types: up to
+// medium_blocks_per_wg(type) blocks of channel (WorkItem.type >> 8) per item.
+void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, int type, float* const out[3],
+                      hipStream_t s) {
+    if (n_items <= 0) return;
+    switch (type) {
+    case 0: hipLaunchKernelGGL(k_idct_dct8, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]); break;
+    case 4: launch_medium_t<16, 16, 4>(f, blocks, items, n_items, out, s); break;
+    case 5: launch_medium_t<32, 32, 5>(f, blocks, items, n_items, out, s); break;
+    case 6: launch_medium_t<16, 8, 6>(f, blocks, items, n_items, out, s); break;
+    case 7: launch_medium_t<8, 16, 7>(f, blocks, items, n_items, out, s); break;
+    case 8: launch_medium_t<32, 8, 8>(f, blocks, items, n_items, out, s); break;
+    case 9: launch_medium_t<8, 32, 9>(f, blocks, items, n_items, out, s); break;
+    case 10: launch_medium_t<32, 16, 10>(f, blocks, items, n_items, out, s); break;
+    case 11: launch_medium_t<16, 32, 11>(f, blocks, items, n_items, out, s); break;
+    case 18: launch_medium_t<64, 64, 18>(f, blocks, items, n_items, out, s); break;
+    case 19: launch_medium_t<64, 32, 19>(f, blocks, items, n_items, out, s); break;
+    case 20: launch_medium_t<32, 64, 20>(f, blocks, items, n_items, out, s); break;
+    default: break;
     }
-    hipLaunchKernelGGL((k_idct_medium<H, W, TYPE>), dim3(n), dim3(256), Cfg::LDS_BYTES, s, f, blocks, items, out[0], out[1],
-                       out[2]);
+}
+
+// the nine special 8x8-footprint types (Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3): whole block in
+// registers, so they get their own launch and register budget
+__global__ __launch_bounds__(64) void k_idct_special(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                     const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    const WorkItem it = items[blockIdx.x];
+    if (threadIdx.x >= it.count) return;
+    const DevBlock b = blocks[it.first + threadIdx.x];
+    switch (it.type & 0xffu) {
+    case 1: special_block<1>(f, b, o0, o1, o2); break;
+    case 2: special_block<2>(f, b, o0, o1, o2); break;
+    case 3: special_block<3>(f, b, o0, o1, o2); break;
+    case 12: special_block<12>(f, b, o0, o1, o2); break;
+    case 13: special_block<13>(f, b, o0, o1, o2); break;
+    case 14: special_block<14>(f, b, o0, o1, o2); break;
+    case 15: special_block<15>(f, b, o0, o1, o2); break;
+    case 16: special_block<16>(f, b, o0, o1, o2); break;
+    case 17: special_block<17>(f, b, o0, o1, o2); break;
+    default: break;
+    }
+}
+
+void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],
+                         hipStream_t s) {
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(k_idct_special, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
 }
 
 int medium_blocks_per_wg(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
-    const int m = h > w ? h : w;
-    const int nb = 256 / (3 * m);
-    return nb > 0 ? nb : 1;
-}
-
-void launch_idct_medium_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items_dev, int n_items, int type,
-                             float* const out[3], hipStream_t s) {
-    if (n_items <= 0) return;
-    switch (type) {
-    case 4: launch_medium_t<16, 16, 4>(f, blocks, items_dev, n_items, out, s); break;
-    case 5: launch_medium_t<32, 32, 5>(f, blocks, items_dev, n_items, out, s); break;
-    case 6: launch_medium_t<16, 8, 6>(f, blocks, items_dev, n_items, out, s); break;
-    case 7: launch_medium_t<8, 16, 7>(f, blocks, items_dev, n_items, out, s); break;
-    case 8: launch_medium_t<32, 8, 8>(f, blocks, items_dev, n_items, out, s); break;
-    case 9: launch_medium_t<8, 32, 9>(f, blocks, items_dev, n_items, out, s); break;
-    case 10: launch_medium_t<32, 16, 10>(f, blocks, items_dev, n_items, out, s); break;
-    case 11: launch_medium_t<16, 32, 11>(f, blocks, items_dev, n_items, out, s); break;
-    case 18: launch_medium_t<64, 64, 18>(f, blocks, items_dev, n_items, out, s); break;
-    case 19: launch_medium_t<64, 32, 19>(f, blocks, items_dev, n_items, out, s); break;
-    case 20: launch_medium_t<32, 64, 20>(f, blocks, items_dev, n_items, out, s); break;
-    default: break;
-    }
+    return 64 / (h > w ? h : w);
 }
 
 // ---- large: 128/256-edge blocks through a scratch plane ---------------------------------------------
@@ -601,25 +752,17 @@ __global__ __launch_bounds__(256) void k_large_dequant(const DevFrame f, const D
         const int y = i / tt.pw, x = i % tt.pw;
         float dq[3];
         dequant_sample(f, k, y, x, dq);
+        if (y < k.dsh && x < k.dsw) {  // finalizeLLF result (k_llf)
+            const int64_t lo = (int64_t)(b.cy + y) * f.bw + b.cx + x;
+            dq[0] = f.llf[0][lo];
+            dq[1] = f.llf[1][lo];
+            dq[2] = f.llf[2][lo];
+        }
         const int64_t off = (int64_t)(k.py0 + y) * f.width + k.px0 + x;
         o0[off] = dq[0];
         o1[off] = dq[1];
         o2[off] = dq[2];
     }
-}
-
-// phase A2: LLF corner (up to 32x32) per (block, channel): grid = (3, nblocks)
-__global__ __launch_bounds__(256) void k_large_llf(const DevFrame f, const DevBlock* __restrict__ blocks, int first, float* o0,
-                                                   float* o1, float* o2) {
-    __shared__ float s0[1024], s1[1024];
-    const DevBlock b = blocks[first + blockIdx.y];
-    const jxl_tt_info tt = JXL_TT[b.type];
-    const int c = blockIdx.x;
-    float* o = c == 0 ? o0 : c == 1 ? o1 : o2;
-    const int64_t base = (int64_t)(b.cy * 8) * f.width + b.cx * 8;
-    const int FW = f.width;
-    llf_block(f, b.cy, b.cx, c, tt.ph >> 3, tt.pw >> 3, s0, s1, threadIdx.x, 256,
-              [&](int ky, int kx, float v) { o[base + (int64_t)ky * FW + kx] = v; });
 }
 
 // phase B: column pass. unit = (block, channel, 64-column strip, 64-output chunk); one wave per unit.
@@ -705,13 +848,12 @@ void launch_idct_large(const DevFrame& f, const DevBlock* blocks, const DevBlock
     if (count <= 0) return;
     // every large type has <= 256x256 samples: 32 workgroups of 256 threads x 8 samples
     hipLaunchKernelGGL(k_large_dequant, dim3(32, count), dim3(256), 0, s, f, blocks, first, out[0], out[1], out[2]);
-    hipLaunchKernelGGL(k_large_llf, dim3(3, count), dim3(256), 0, s, f, blocks, first, out[0], out[1], out[2]);
     // at most (256/64)*(256/64) = 16 units per (block, channel)
     hipLaunchKernelGGL(k_large_colpass, dim3(16, 3, count), dim3(64), 0, s, f, blocks, first, out[0], out[1], out[2],
                        scratch[0], scratch[1], scratch[2]);
     hipLaunchKernelGGL(k_large_rowpass, dim3(16, 3, count), dim3(64), 0, s, f, blocks, first, scratch[0], scratch[1],
                        scratch[2], out[0], out[1], out[2]);
-    if (n_launches) *n_launches += 4;
+    if (n_launches) *n_launches += 3;
 }
 
 __global__ void k_accumulate(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n) {
