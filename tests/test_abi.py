@@ -1,0 +1,80 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/jxlatte_amd.h declares; the
+Python mirror of the transform-type table matches the C table; host-side squeeze bookkeeping (no
+device needed) matches the oracle and the Python restatement in synth."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from jxlatte_amd import _lib, abi, host, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "jxlatte_amd.h")).read()
+    declared = set(re.findall(r"\b(jxl_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, "symbols declared in the header but not exported: %s" % missing
+    # the binding table covers exactly the declared functions
+    assert declared == set(_lib.SIGNATURES.keys())
+    assert b"gfx950" in lib.jxl_version()
+
+
+def test_no_device_fails_loudly():
+    """no GPU in the build container: creating a context must fail with a device error, never fall back"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.JxlError) as e:
+        _lib.Context(0)
+    assert e.value.status == abi.JXL_ERR_DEVICE
+
+
+def test_transform_type_table_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "jxl_transform_types.h")).read()
+    rows = re.findall(r"\{(\d+), (\d+), (\d+), JXL_METHOD_(\w+), (\d+), (\d+)\},\s*/\* (\w+) \*/", hdr)
+    assert len(rows) == 27
+    methods = {"DCT": 0, "DCT2": 1, "DCT4": 2, "HORNUSS": 3, "DCT8_4": 4, "DCT4_8": 5, "AFV": 6}
+    for (t, p, o, m, ph, pw, name), py in zip(rows, abi.TRANSFORM_TYPES):
+        assert (name, int(t), int(p), int(o), methods[m], int(ph), int(pw)) == py
+
+
+def test_struct_sizes_match_c_layout():
+    # computed by hand from the header: all members are 4-byte scalars / arrays
+    assert C.sizeof(abi.VarDCTParams) == 4 * (3 + 3 + 3 + 1 + 2 + 1 + 1 + 3 + 3 + 1 + 1 + 8 + 3 + 3 + 1 + 9 + 3 + 3 + 1 + 2)
+    assert C.sizeof(abi.SqueezeParam) == 16
+    assert C.sizeof(abi.Channel) == 16
+    assert C.sizeof(abi.LFGroupDesc) == 16 + 6 * 8 + 8 + 3 * 8
+
+
+@pytest.mark.parametrize("shape,channels", [((1080, 1920), 3), ((4320, 7680), 3), ((9, 9), 1), ((600, 37), 4), ((8, 8), 3), ((1, 5000), 2)])
+def test_default_squeeze_params_three_ways(orc, shape, channels):
+    shapes = [shape] * channels
+    a = host.ModularStream.defaultSqueezeParams(shapes)       # C-ABI
+    b = synth.default_squeeze_params(shapes)                   # Python host logic
+    c = orc.default_squeeze_params(shapes)                     # oracle
+    assert a == b == c
+    ea = host.ModularStream.squeezedShapes(shapes, a)
+    assert ea == synth.squeezed_shapes(shapes, a) == orc.squeezed_shapes(shapes, a)
+    # inverse bookkeeping returns to the image channels
+    assert orc.inverse_shapes(ea, a) == shapes
+
+
+def test_default_squeeze_plan_1080p_has_18_steps():
+    sp = synth.default_squeeze_params([(1080, 1920)] * 3)
+    assert len(sp) == 18 and sp[0] == (1, 0, 1, 2) and sp[1] == (0, 0, 1, 2)
+    assert len(synth.default_squeeze_params([(4320, 7680)] * 3)) == 22
+
+
+def test_weights_layout():
+    from jxlatte_amd import hfglobal
+    w, offs = hfglobal.default_weights()
+    assert w.dtype == np.float32 and w.size == 3 * 131584 and offs.shape == (51,)
+    assert np.all(np.isfinite(w)) and np.all(w > 0)
+    # DCT8 luma DC weight = 1 / 560
+    assert w[offs[1]] == np.float32(1.0) / np.float32(560.0)

@@ -1,0 +1,110 @@
+"""GPU parity of the Modular path (inverse Squeeze steps, RCT, int->float): bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from jxlatte_amd import _lib, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("h,aw,rw", [(1, 1, 0), (1, 1, 1), (3, 2, 1), (64, 64, 64), (65, 33, 32), (200, 129, 129), (7, 500, 499), (1080, 960, 960)])
+def test_inv_hsqueeze(ctx, orc, h, aw, rw):
+    rng = np.random.default_rng(h * 3 + aw)
+    avg = rng.integers(-3000, 3000, size=(h, aw)).astype(np.int32)
+    res = np.rint(rng.laplace(0, 40, size=(h, rw))).astype(np.int32)
+    assert_bits_equal(host.ModularChannel.inverseHorizontalSqueeze(ctx, avg, res), orc.inv_hsqueeze(avg, res), "hsq")
+
+
+@pytest.mark.parametrize("w,ah,rh", [(1, 1, 0), (1, 1, 1), (3, 2, 1), (64, 64, 64), (65, 33, 32), (200, 129, 129), (500, 7, 6), (1920, 540, 540)])
+def test_inv_vsqueeze(ctx, orc, w, ah, rh):
+    rng = np.random.default_rng(w * 3 + ah)
+    avg = rng.integers(-3000, 3000, size=(ah, w)).astype(np.int32)
+    res = np.rint(rng.laplace(0, 40, size=(rh, w))).astype(np.int32)
+    assert_bits_equal(host.ModularChannel.inverseVerticalSqueeze(ctx, avg, res), orc.inv_vsqueeze(avg, res), "vsq")
+
+
+def test_squeeze_wraparound_and_tendency_branches(ctx, orc):
+    big = np.array([[2 ** 31 - 1, -2 ** 31, 2 ** 31 - 5, 17, -2 ** 31 + 3, 0, 2 ** 30, -2 ** 30]], np.int32)
+    res = np.array([[2 ** 31 - 1, -2 ** 31, 12345, -98765, 2 ** 30, -7, 3, 2 ** 31 - 1]], np.int32)
+    assert_bits_equal(host.ModularChannel.inverseHorizontalSqueeze(ctx, big, res), orc.inv_hsqueeze(big, res), "wrap h")
+    assert_bits_equal(host.ModularChannel.inverseVerticalSqueeze(ctx, big.T.copy(), res.T.copy()), orc.inv_vsqueeze(big.T.copy(), res.T.copy()), "wrap v")
+    ramp = np.arange(0, 640, 10, dtype=np.int32).reshape(1, 64)
+    for a in (ramp, -ramp, ramp[:, ::-1].copy()):
+        r = np.zeros_like(a)
+        assert_bits_equal(host.ModularChannel.inverseHorizontalSqueeze(ctx, a, r), orc.inv_hsqueeze(a, r), "ramp")
+
+
+def test_squeeze_shape_errors(ctx):
+    with pytest.raises((ValueError, _lib.IllegalArgumentException)):
+        host.ModularChannel.inverseHorizontalSqueeze(ctx, np.zeros((4, 5), np.int32), np.zeros((4, 3), np.int32))
+    with pytest.raises((RuntimeError, _lib.IllegalStateException)):
+        host.ModularChannel.inverseVerticalSqueeze(ctx, np.zeros((5, 4), np.int32), np.zeros((3, 4), np.int32))
+
+
+@pytest.mark.parametrize("rct_type", [0, 1, 2, 3, 4, 5, 6, 7 + 3, 14 + 6, 35 + 5, 41])
+def test_rct(ctx, orc, rct_type):
+    v = np.random.default_rng(rct_type).integers(-2 ** 31, 2 ** 31 - 1, size=(3, 19, 23)).astype(np.int32)
+    assert_bits_equal(host.rct(ctx, v, rct_type), orc.rct(v, rct_type), "rct %d" % rct_type)
+
+
+def test_modular_to_float(ctx, orc):
+    rng = np.random.default_rng(3)
+    a = rng.integers(-70000, 70000, size=(31, 17)).astype(np.int32)
+    b = rng.integers(-70000, 70000, size=(31, 17)).astype(np.int32)
+    assert_bits_equal(host.modularToFloat(ctx, a, None, 0.0037), orc.modular_to_float(a, None, 0.0037), "to float")
+    assert_bits_equal(host.modularToFloat(ctx, a, b, 1.0 / 255), orc.modular_to_float(a, b, 1.0 / 255), "to float sum")
+
+
+@pytest.mark.parametrize("w,h,ch", [(1, 1, 3), (8, 8, 3), (9, 9, 1), (53, 37, 3), (37, 130, 4), (640, 360, 3), (1920, 1080, 3)])
+def test_apply_transforms_default_plan(ctx, orc, w, h, ch):
+    mod = synth.make_modular_frame(w, h, channels=ch, seed=w + h)
+    ms = host.ModularStream(ctx, mod["chans"], mod["sp"])
+    out = ms.applyTransforms()
+    exp = orc.modular_apply(mod["chans"], mod["sp"])
+    assert len(out) == len(exp) == ch
+    for i, (a, b) in enumerate(zip(out, exp)):
+        assert_bits_equal(a, b, "channel %d of %dx%d" % (i, w, h))
+    assert ms.applyTransforms() is ms.channels  # second call is a no-op, like ModularStream.transformed
+
+
+def test_apply_transforms_with_rct_and_rerun(ctx, orc):
+    mod = synth.make_modular_frame(100, 60, channels=3, seed=5)
+    ms = host.ModularStream(ctx, mod["chans"], mod["sp"], rctType=6 + 7 * 2, rctBegin=0)
+    ms.begin()
+    ms.run()
+    first = ms.getDecodedBuffer()
+    ms.run()  # re-runnable: inputs are not consumed
+    second = ms.getDecodedBuffer()
+    exp = orc.modular_apply(mod["chans"], mod["sp"], rct_type=6 + 7 * 2, rct_begin=0)
+    for a, b, c in zip(first, second, exp):
+        assert_bits_equal(a, c, "rct run 1")
+        assert_bits_equal(b, c, "rct run 2")
+    # RCT only (no squeeze): must not modify the caller's input
+    v = [np.random.default_rng(i).integers(0, 256, size=(12, 20)).astype(np.int32) for i in range(3)]
+    keep = [a.copy() for a in v]
+    ms2 = host.ModularStream(ctx, v, [], rctType=10, rctBegin=0)
+    out = ms2.applyTransforms()
+    e = orc.rct(np.stack(keep), 10)
+    for i in range(3):
+        assert_bits_equal(out[i], e[i], "rct only")
+        assert np.array_equal(v[i], keep[i])
+
+
+def test_squeeze_round_trip_property_full_size(ctx, orc):
+    """size-independent property at BASELINE's 8K Modular size: inverse(forward(x)) == x on the GPU
+    (forward steps are the oracle's test-only forward squeeze)"""
+    h, w, ch = 4320, 7680, 1
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 65536, size=(h, w)).astype(np.int32)
+    sp = synth.default_squeeze_params([(h, w)] * ch)
+    chans = [img]
+    for (horiz, in_place, begin, num) in sp:
+        end = begin + num - 1
+        offset = end + 1 if in_place else len(chans)
+        for k in range(begin, end + 1):
+            a, r = (orc.fwd_hsqueeze if horiz else orc.fwd_vsqueeze)(chans[k])
+            chans[k] = a
+            chans.insert(offset + k - begin, r)
+    out = host.ModularStream(ctx, chans, sp).applyTransforms()
+    assert len(out) == 1 and np.array_equal(out[0], img)
