@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--distinct-frames", type=int, default=2, help="distinct synthetic frames generated per rank (the rest reuse them)")
     ap.add_argument("--mix", default="default")
     ap.add_argument("--epf-iters", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=1, help="1 = all frames of a rank share one HIP stream")
+    ap.add_argument("--streams", type=int, default=0, help="0 = one HIP stream per frame context (default); 1 = all frames of a rank share one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check frame 0 against the oracle before timing")
@@ -127,12 +127,23 @@ def main():
     value = total_px / elapsed / 1e6  # Mpixels/s, whole job
 
     # HIP-event stage times of ctx 0 (averaged over its runs inside the timed region)
-    ms_all, ms_idct, ms_rest = C.c_float(), C.c_float(), C.c_float()
-    ctxs[0].call("jxl_vardct_last_stage_ms", 0, C.byref(ms_all))
-    ctxs[0].call("jxl_vardct_last_stage_ms", 1, C.byref(ms_idct))
-    ctxs[0].call("jxl_vardct_last_stage_ms", 2, C.byref(ms_rest))
-    ctxs[0].call("jxl_vardct_enable_stage_timing", 0)
+    def stage_ms():
+        out = []
+        for which in (0, 1, 2):
+            v = C.c_float()
+            ctxs[0].call("jxl_vardct_last_stage_ms", which, C.byref(v))
+            out.append(v.value)
+        return out
+    ms_all_b, ms_idct_b, ms_rest_b = stage_ms()  # inside the timed region (other frames' kernels overlap)
     launches = frames[0].lastLaunchCount()
+    # the same events with frame 0 alone on the device: the kernels' own durations (what rocprofv3 reports per launch)
+    torch.cuda.synchronize()
+    ctxs[0].call("jxl_vardct_enable_stage_timing", 1)
+    for _ in range(max(5, min(args.steps, 30))):
+        frames[0].run()
+        ctxs[0].synchronize()
+    ms_all, ms_idct, ms_rest = stage_ms()
+    ctxs[0].call("jxl_vardct_enable_stage_timing", 0)
 
     # single-frame latency (one frame alone on the device)
     lat = []
@@ -173,17 +184,18 @@ def main():
     side = 21.0 / 64.0  # per-pixel share of the 8x8-cell side info
     path_bytes = (12.0 + out_bytes_px + side) * npx + 1.58e6  # whole path, algorithmic (24.5 B/px for f32 out)
     rest_bytes = (12.0 + out_bytes_px + 8.0 / 64.0) * npx     # restore stage: planes in + planes out + hfMul/sharpness
-    rest_s = ms_rest.value * 1e-3
+    rest_s = ms_rest * 1e-3
     achieved = rest_bytes / rest_s / 1e9 if rest_s > 0 else 0.0
     path_gbs = path_bytes * fpg * args.steps / elapsed / 1e9
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "restoration+colour stage (Gab, EPF x%d, XYB)" % args.epf_iters,
-        "kernel_ms": round(ms_rest.value, 4), "algorithmic_bytes_per_launch": int(rest_bytes),
-        "idct_stage_ms": round(ms_idct.value, 4), "frame_ms_events": round(ms_all.value, 4),
+        "kernel": "k_restore_fused (Gab, EPF x%d, XYB): HIP events around the launch, frame 0 alone on the device" % args.epf_iters,
+        "kernel_ms": round(ms_rest, 4), "algorithmic_bytes_per_launch": int(rest_bytes),
+        "kernel_ms_in_batch": round(ms_rest_b, 4),
+        "idct_stage_ms": round(ms_idct, 4), "idct_stage_ms_in_batch": round(ms_idct_b, 4), "frame_ms_events": round(ms_all, 4),
         "path_algorithmic_GBps": round(path_gbs, 1), "path_frac": round(path_gbs / HBM_PEAK_GBS, 4),
-        "note": "EPF is VALU-bound (non-fused f32, reference summation order): see DESIGN.md",
+        "note": "this kernel is VALU-bound, not HBM-bound: ~430 non-fusable f32 ops/px in the reference's order (DESIGN.md 4.2)",
     }
 
     cpu = None
@@ -211,7 +223,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d independent %dx%d VarDCT frames per GPU (mix=%s, Gab + EPF x%d + XYB, %s out), inputs resident in HBM"
                                % (args.workload, fpg, W, H, args.mix, args.epf_iters, "f32" if out_bytes_px == 12.0 else "PQ u16"),
-                   "frames_per_gpu": fpg, "distinct_frames": len(distinct), "streams": args.streams,
+                   "frames_per_gpu": fpg, "distinct_frames": len(distinct), "streams": args.streams if args.streams else fpg,
                    "varblock_area_share": synth.type_histogram(distinct[0]), "kernel_launches_per_frame": launches,
                    "single_frame_ms": round(single_ms, 4),
                    "single_frame_Mpx_s": round(npx / single_ms / 1e3, 1), "input_gen_s": round(gen_s, 1)},
