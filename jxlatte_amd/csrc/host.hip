@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -94,7 +95,8 @@ struct jxl_ctx {
     bool owns_stream = true;
     // fork/join side streams: the per-type IDCT kernels are independent and individually too small to fill
     // 256 CUs, so they run concurrently
-    static constexpr int kAux = 4;
+    static constexpr int kAux = 12;
+    int n_aux = 1;  // side streams in use (JXL_AUX_STREAMS overrides). 1 is the batch-throughput optimum; 3 gives the lowest single-frame latency
     hipStream_t aux[kAux] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kAux] = {};
 
@@ -365,7 +367,8 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
-    for (int i = 0; i < jxl_ctx::kAux; i++) {
+    if (const char* e = getenv("JXL_AUX_STREAMS")) c->n_aux = std::max(0, std::min((int)jxl_ctx::kAux, atoi(e)));
+    for (int i = 0; i < c->n_aux; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming);
     }
@@ -594,11 +597,11 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         }
         // fork: every type kernel writes a disjoint set of varblocks
         const int n_k = (int)c->type_launches.size() + (c->n_special_items > 0 ? 1 : 0);
-        const bool fork = n_k > 1;
+        const bool fork = n_k > 1 && c->n_aux > 0;
         int used = 0;
         if (fork) {
             (void)hipEventRecord(c->fork_ev, s);
-            used = std::min(n_k - 1, (int)jxl_ctx::kAux);
+            used = std::min(n_k - 1, c->n_aux);
             for (int i = 0; i < used; i++) (void)hipStreamWaitEvent(c->aux[i], c->fork_ev, 0);
         }
         int k = 0;
