@@ -218,7 +218,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     for (int t : kOrder) {
         if (sm[t].empty()) continue;
         jxl_ctx::TypeLaunch tl{t, (int)items.size(), 0};
-        if (t == 0) {
+        if (t == 0 && getenv("JXL_DCT8_LANEBLOCK")) {
             for (uint32_t o = 0; o < sm[t].size(); o += 64)
                 items.push_back(WorkItem{(uint32_t)t, first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
         } else {

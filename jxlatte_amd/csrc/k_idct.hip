@@ -21,6 +21,7 @@
 //            scratch plane, 64x64 register tiles per wave.
 #include "jxl_internal.h"
 #include "../../include/jxl_tables.h"
+#include <cstdlib>
 
 namespace jxl {
 
@@ -691,7 +692,10 @@ void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem*
                       hipStream_t s) {
     if (n_items <= 0) return;
     switch (type) {
-    case 0: hipLaunchKernelGGL(k_idct_dct8, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]); break;
+    case 0:
+        if (getenv("JXL_DCT8_LANEBLOCK")) hipLaunchKernelGGL(k_idct_dct8, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
+        else launch_medium_t<8, 8, 0>(f, blocks, items, n_items, out, s);
+        break;
     case 4: launch_medium_t<16, 16, 4>(f, blocks, items, n_items, out, s); break;
     case 5: launch_medium_t<32, 32, 5>(f, blocks, items, n_items, out, s); break;
     case 6: launch_medium_t<16, 8, 6>(f, blocks, items, n_items, out, s); break;

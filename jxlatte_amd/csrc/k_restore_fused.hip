@@ -278,38 +278,62 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
         }
         sig[threadIdx.x & 255] = v;
     }
-    // load the input tile: clamped coordinates feed Gab, mirrored ones feed EPF directly
-    for (int i = threadIdx.x; i < G::IW * G::IH; i += NTHR) {
-        const int y = i / G::IW, x = i % G::IW;
-        int gy = tc.iy0 + y, gx = tc.ix0 + x;
-        if (tc.edge) {
-            if (GAB) {
-                gy = min(max(gy, 0), H - 1);
-                gx = min(max(gx, 0), W - 1);
-            } else {
-                gy = mirror_c(gy, H);
-                gx = mirror_c(gx, W);
+    // load the input tile: clamped coordinates feed Gab, mirrored ones feed EPF directly. Flat row-major
+    // walk with incrementally updated (y, x) and 32-bit plane offsets (scalar base + 32-bit lane offset).
+    {
+        constexpr int STEP_Y = NTHR / G::IW, STEP_X = NTHR % G::IW;
+        int y = threadIdx.x / G::IW, x = threadIdx.x % G::IW;
+        const float* __restrict__ in0 = a.in[0];
+        const float* __restrict__ in1 = a.in[1];
+        const float* __restrict__ in2 = a.in[2];
+        while (y < G::IH) {
+            int gy = tc.iy0 + y, gx = tc.ix0 + x;
+            if (tc.edge) {
+                if (GAB) {
+                    gy = min(max(gy, 0), H - 1);
+                    gx = min(max(gx, 0), W - 1);
+                } else {
+                    gy = mirror_c(gy, H);
+                    gx = mirror_c(gx, W);
+                }
+            }
+            const uint32_t g = (uint32_t)(gy * W + gx);
+            const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
+            float* d = A + y * G::SW + x;
+            d[0] = v0;
+            d[G::PLANE] = v1;
+            d[2 * G::PLANE] = v2;
+            x += STEP_X;
+            y += STEP_Y;
+            if (x >= G::IW) {
+                x -= G::IW;
+                y++;
             }
         }
-        const int64_t g = (int64_t)gy * W + gx;
-#pragma unroll
-        for (int c = 0; c < 3; c++) A[c * G::PLANE + y * G::SW + x] = a.in[c][g];
     }
     __syncthreads();
     float* cur = A;
     float* oth = B;
     int m = 0;
-    if (GAB) {  // Frame.performGabConvolution (:505-542)
+    if (GAB) {  // Frame.performGabConvolution (:505-542): lane = pixel (consecutive lanes = consecutive x: conflict-free
+                // LDS rows, perfectly balanced; a 4x1 register-patch form measured 6% slower on the whole kernel)
         m = 1;
-        const int rw = G::IW - 2, rh = G::IH - 2;
-        for (int i = threadIdx.x; i < rw * rh; i += NTHR) {
-            const int y = 1 + i / rw, x = 1 + i % rw;
+        constexpr int rw = G::IW - 2, rh = G::IH - 2;
+        constexpr int STEP_Y = NTHR / rw, STEP_X = NTHR % rw;
+        int y = threadIdx.x / rw, x = threadIdx.x % rw;
+        while (y < rh) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float* p = cur + c * G::PLANE + y * G::SW + x;
+                const float* p = cur + c * G::PLANE + (y + 1) * G::SW + x + 1;
                 const float adj = p[-1] + p[1] + p[-G::SW] + p[G::SW];
                 const float diag = p[-G::SW - 1] + p[-G::SW + 1] + p[G::SW - 1] + p[G::SW + 1];
-                oth[c * G::PLANE + y * G::SW + x] = a.p.gab_base[c] * p[0] + a.p.gab_adj[c] * adj + a.p.gab_diag[c] * diag;
+                oth[c * G::PLANE + (y + 1) * G::SW + x + 1] = a.p.gab_base[c] * p[0] + a.p.gab_adj[c] * adj + a.p.gab_diag[c] * diag;
+            }
+            x += STEP_X;
+            y += STEP_Y;
+            if (x >= rw) {
+                x -= rw;
+                y++;
             }
         }
         if (tc.edge && ITERS > 0) mirror_fixup<G, NTHR>(oth, m, G::RE, tc);
@@ -333,7 +357,7 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
             v1 = xp.sm[3] * mixL + xp.sm[4] * mixM + xp.sm[5] * mixS;
             v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
         }
-        const int64_t g = (int64_t)gy * W + gx;
+        const uint32_t g = (uint32_t)(gy * W + gx);
         float v[3] = {v0, v1, v2};
         if (PLAIN) {
 #pragma unroll
