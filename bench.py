@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="0 = one HIP stream per frame context (default); 1 = all frames of a rank share one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--stages", type=int, default=31, help="stage mask (diagnostics): 1 IDCT, 2 Gab, 4 EPF, 8 XYB, 16 out")
     ap.add_argument("--verify", action="store_true", help="check frame 0 against the oracle before timing")
     return ap.parse_args()
 
@@ -80,7 +81,7 @@ def main():
         if args.streams == 1 and ctxs:
             c.call("jxl_ctx_set_stream", ctxs[0].stream)
         ctxs.append(c)
-        frames.append(host.Frame.from_synth(c, distinct[i % len(distinct)]))
+        frames.append(host.Frame.from_synth(c, distinct[i % len(distinct)], stages=args.stages))
     gen_s = time.time() - t0
     npx = W * H
     lib = _lib.load()

@@ -213,20 +213,15 @@ jxl_status finalize_tables(jxl_ctx* c) {
             first_of[t] = (uint32_t)c->h_blocks.size();
             c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
         }
-    static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};
+    static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     c->type_launches.clear();
     for (int t : kOrder) {
         if (sm[t].empty()) continue;
         jxl_ctx::TypeLaunch tl{t, (int)items.size(), 0};
-        if (t == 0 && getenv("JXL_DCT8_LANEBLOCK")) {
-            for (uint32_t o = 0; o < sm[t].size(); o += 64)
-                items.push_back(WorkItem{(uint32_t)t, first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
-        } else {
-            const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
-            for (uint32_t o = 0; o < sm[t].size(); o += nb)
-                for (uint32_t ch = 0; ch < 3; ch++)
-                    items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(nb, sm[t].size() - o)});
-        }
+        const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
+        for (uint32_t o = 0; o < sm[t].size(); o += nb)
+            for (uint32_t ch = 0; ch < 3; ch++)
+                items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(nb, sm[t].size() - o)});
         tl.n_items = (int)items.size() - tl.items_off;
         c->type_launches.push_back(tl);
     }

@@ -73,9 +73,8 @@ struct XybParams {
 };
 
 // ---- launchers (defined in the kernel TUs) ---------------------------------------------------
-// One launch per transform type present (own register budget per type). WorkItem.type = TransformType.type |
-// channel << 8: medium items cover medium_blocks_per_wg(type) blocks of one channel (one wave); DCT8 items
-// cover up to 64 blocks, all channels.
+// One launch per transform type present (256-thread workgroups). WorkItem.type = TransformType.type | channel << 8;
+// an item covers up to medium_blocks_per_wg(type) blocks of that channel.
 void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, int type, float* const out[3],
                       hipStream_t s);
 // the special 8x8-footprint types: items of up to 64 blocks (one per lane)

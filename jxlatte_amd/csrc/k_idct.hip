@@ -27,6 +27,8 @@ namespace jxl {
 
 #include "lut_small.inc"
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 static constexpr float kAfv[16][16] = JXL_AFV_BASIS_INIT;
 __constant__ float kLlfScale[32] = JXL_LLF_SCALE_INIT;
 
@@ -221,6 +223,18 @@ __device__ __forceinline__ void invert_small(const float* co, float* px) {
 // HFCoefficients.dequantizeHFCoefficients inner expression (HFCoefficients.java:309-315)
 __device__ __forceinline__ float dequant1(int32_t q, float qb, float qbn, float sfc, float w) {
     const float quant = (q > -2 && q < 2) ? (q == 0 ? 0.0f : (q > 0 ? qb : -qb)) : (float)q - qbn / (float)q;
+    return quant * sfc * w;
+}
+
+// Same value as dequant1, but qbn/(float)q comes from a 64-entry table of qbn/(float)|q| (built once per wave with
+// the same correctly rounded division; x/(-y) == -(x/y) exactly in IEEE arithmetic), so the ~12-instruction
+// division sequence runs only for |q| >= 64.
+__device__ __forceinline__ float dequant1_tab(int32_t q, float qb, float qbn, float sfc, float w, const float* __restrict__ tab) {
+    const int aq = q < 0 ? -q : q;
+    float t;
+    if (aq < 64) t = tab[aq];
+    else t = qbn / (float)aq;
+    const float quant = aq < 2 ? (q == 0 ? 0.0f : (q > 0 ? qb : -qb)) : (float)q - (q > 0 ? t : -t);
     return quant * sfc * w;
 }
 
@@ -529,21 +543,25 @@ struct MediumCfg {
     static constexpr int BPW = 64 / MAXD;  // blocks per wave
     static constexpr int LD = W + 1;       // padded row stride
     static constexpr int IMG = H * LD;     // floats per block image
-    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(BPW * IMG);
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(4 * BPW * IMG + 64);  // 4 waves + qbn/|q| table
 };
 
 template <int H, int W, int TYPE>
 __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* __restrict__ blocks, const WorkItem it,
-                                            float* __restrict__ lds, float* __restrict__ o0, float* __restrict__ o1,
+                                            float* __restrict__ lds_wg, float* __restrict__ o0, float* __restrict__ o1,
                                             float* __restrict__ o2) {
     using Cfg = MediumCfg<H, W>;
     constexpr int LD = Cfg::LD, IMG = Cfg::IMG;
     constexpr int PI = JXL_TT[TYPE].param_index;
     constexpr bool FLIP = H >= W;  // TransformType.flip() for METHOD_DCT
     constexpr int DSH = H / 8, DSW = W / 8;
-    const int nb = (int)it.count;
+    // the 4 waves of the workgroup are independent: wave w owns blocks [w*BPW, (w+1)*BPW) of the item
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wfirst = (int)it.first + wave * Cfg::BPW;
+    const int nb = min(max((int)it.count - wave * Cfg::BPW, 0), Cfg::BPW);
     const int c = (int)(it.type >> 8);  // channel of this item
-    const int lane = threadIdx.x;
+    float* lds = lds_wg + wave * (Cfg::BPW * IMG);
     const int FW = f.width;
     float* out = c == 0 ? o0 : c == 1 ? o1 : o2;
     const int* qc_plane = f.coeff[c];
@@ -552,12 +570,15 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
     const float* wc = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + c];
     const float* wy = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + 1];
     const float qbn = f.quant_bias_numerator;
+    float* qtab = lds_wg + 4 * Cfg::BPW * IMG;
+    if (wave == 0) qtab[lane] = lane > 0 ? qbn / (float)lane : 0.0f;
+    __syncthreads();
 
     // ---- column pass
     {
         const int bi = lane / W, x = lane % W;
         if (bi < nb) {
-            const DevBlock b = blocks[it.first + bi];
+            const DevBlock b = blocks[wfirst + bi];
             const int py0 = b.cy * 8, px0 = b.cx * 8;
             const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
             const float sfc = f.scale_factor[c] / hfm, sfy = f.scale_factor[1] / hfm;
@@ -567,7 +588,7 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
             const float* lfp = f.lf[c] + (int64_t)b.cy * f.bw + b.cx;
             const float* lut = f.lut + lut_off(ceil_log2_dev(H));
             float kcfl = 0.0f;
-            float acc[H];
+            v2f acc[H / 2];
             // rows in chunks of RC: all global loads of a chunk are issued before its arithmetic, so RC (x2-4)
             // loads per lane are in flight instead of one dependent load per row
             constexpr int RC = 8;
@@ -598,49 +619,56 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
                     if (n < DSH && x < DSW) {
                         co = llf_coeff<DSH, DSW>(f, lfp, n, x);  // finalizeLLF (:194-229)
                     } else {
-                        co = dequant1(qcv[r], qbc, qbn, sfc, wcv[r]);
+                        co = dequant1_tab(qcv[r], qbc, qbn, sfc, wcv[r], qtab);
                         if (c != 1) {
-                            const float dy = dequant1(qyv[r], qby, qbn, sfy, wyv[r]);
+                            const float dy = dequant1_tab(qyv[r], qby, qbn, sfy, wyv[r], qtab);
                             co = co + kcfl * dy;  // chromaFromLuma (:186-188)
                         }
                     }
+                    // packed f32: two outputs per instruction (v_pk_mul_f32 + v_pk_add_f32; still one rounding per
+                    // multiply and per add, same order per output)
+                    const v2f co2 = {co, co};
                     if (n == 0) {
 #pragma unroll
-                        for (int k = 0; k < H; k++) acc[k] = co;
+                        for (int k = 0; k < H / 2; k++) acc[k] = co2;
                     } else {
-                        const float* lr = lut + (n - 1) * H;
+                        const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * H);
 #pragma unroll
-                        for (int k = 0; k < H; k++) acc[k] = acc[k] + co * lr[k];
+                        for (int k = 0; k < H / 2; k++) acc[k] = acc[k] + co2 * lr[k];
                     }
                 }
             }
             float* dcol = lds + bi * IMG + x;
 #pragma unroll
-            for (int k = 0; k < H; k++) dcol[k * LD] = acc[k];
+            for (int k = 0; k < H / 2; k++) {
+                dcol[(2 * k) * LD] = acc[k].x;
+                dcol[(2 * k + 1) * LD] = acc[k].y;
+            }
         }
     }
-    __syncthreads();  // one wave per workgroup: orders the LDS image for the row pass
+    __syncthreads();  // orders the wave's LDS image for the row pass (all 4 waves run the same sequence)
     // ---- row pass
     {
         const int bi = lane / H, y = lane % H;
         if (bi < nb) {
-            const DevBlock b = blocks[it.first + bi];
+            const DevBlock b = blocks[wfirst + bi];
             const float* row = lds + bi * IMG + y * LD;
             const float* lut = f.lut + lut_off(ceil_log2_dev(W));
-            float acc[W];
+            v2f acc[W / 2];
             const float s0 = row[0];
 #pragma unroll
-            for (int k = 0; k < W; k++) acc[k] = s0;
+            for (int k = 0; k < W / 2; k++) acc[k] = v2f{s0, s0};
 #pragma unroll 8
             for (int n = 1; n < W; n++) {
                 const float s2 = row[n];
-                const float* lr = lut + (n - 1) * W;
+                const v2f s22 = {s2, s2};
+                const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * W);
 #pragma unroll
-                for (int k = 0; k < W; k++) acc[k] = acc[k] + s2 * lr[k];
+                for (int k = 0; k < W / 2; k++) acc[k] = acc[k] + s22 * lr[k];
             }
             float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8;
 #pragma unroll
-            for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(o + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+            for (int k = 0; k < W / 2; k += 2) *reinterpret_cast<float4*>(o + 2 * k) = make_float4(acc[k].x, acc[k].y, acc[k + 1].x, acc[k + 1].y);
         }
     }
 }
@@ -663,52 +691,193 @@ void launch_llf(const DevFrame& f, const DevBlock* blocks, int first, int count,
     hipLaunchKernelGGL(k_llf, dim3(3, count), dim3(256), 0, s, f, blocks, first, llf[0], llf[1], llf[2]);
 }
 
-// ---- launches: one kernel per transform type present, each with its own register budget -------------------
-// (a single merged kernel would be allocated the registers of its most demanding branch -- the 64-point
-// accumulators -- and leave the common small types at 2 waves/SIMD; these kernels are latency-sensitive)
-__global__ __launch_bounds__(64) void k_idct_dct8(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                  const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
-    const WorkItem it = items[blockIdx.x];
-    if (threadIdx.x < it.count) dct8_block(f, blocks[it.first + threadIdx.x], o0, o1, o2);
-}
+// ---- 64-point family (64x64, 64x32, 32x64): one 256-thread workgroup per NBLK blocks of one channel ---------
+// A 64-point column/row has 63 x 64 multiply-adds; one lane per column would serialise 8k dependent-issue
+// instructions per pass. Here the dequantised coefficients are staged once in LDS and every 1-D transform is
+// split over `chunks` waves, each lane producing KC = 16 outputs of its column / row; a wave's lanes share the
+// output chunk, so the LUT slice stays wave-uniform (scalar loads). Two LDS images (ping-pong).
+template <int H, int W>
+struct Wg64Cfg {
+    static constexpr int NBLK = 64 / (H < W ? H : W);  // blocks per workgroup
+    static constexpr int LD = W + 1;
+    static constexpr int IMG = H * LD;
+    static constexpr int CH_COL = 256 / (NBLK * W), KC_COL = H / CH_COL;  // column pass: chunks, outputs per lane
+    static constexpr int CH_ROW = 256 / (NBLK * H), KC_ROW = W / CH_ROW;
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(2 * NBLK * IMG + 64);
+};
 
 template <int H, int W, int TYPE>
-__global__ __launch_bounds__(64) void k_idct_medium(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                    const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+__device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __restrict__ blocks, const WorkItem it,
+                                          float* __restrict__ lds, float* __restrict__ o0, float* __restrict__ o1,
+                                          float* __restrict__ o2) {
+    using Cfg = Wg64Cfg<H, W>;
+    constexpr int NBLK = Cfg::NBLK, LD = Cfg::LD, IMG = Cfg::IMG;
+    constexpr int PI = JXL_TT[TYPE].param_index;
+    constexpr bool FLIP = H >= W;
+    constexpr int DSH = H / 8, DSW = W / 8;
+    const int nb = (int)it.count;
+    const int c = (int)(it.type >> 8);
+    const int tid = threadIdx.x;
+    const int FW = f.width;
+    float* out = c == 0 ? o0 : c == 1 ? o1 : o2;
+    float* img0 = lds;               // dequantised coefficients, later the row-pass input
+    float* img1 = lds + NBLK * IMG;  // column-pass output
+    float* qtab = lds + 2 * NBLK * IMG;
+    const float qbn = f.quant_bias_numerator;
+    if (tid < 64) qtab[tid] = tid > 0 ? qbn / (float)tid : 0.0f;
+    __syncthreads();
+    // 1. dequant + CfL + LLF -> img0 (lane = column, rows strided over the workgroup: coalesced rows)
+    {
+        const float* wc = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + c];
+        const float* wy = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + 1];
+        constexpr int RSTEP = 256 / W;  // rows covered per sweep
+        const int x = tid % W, r0 = tid / W;
+        for (int bi = 0; bi < nb; bi++) {
+            const DevBlock b = blocks[it.first + bi];
+            const int py0 = b.cy * 8, px0 = b.cx * 8;
+            const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+            const float sfc = f.scale_factor[c] / hfm, sfy = f.scale_factor[1] / hfm;
+            const float qbc = f.quant_bias[c], qby = f.quant_bias[1];
+            const int ty0 = py0 >> 6, tx0 = px0 >> 6, tx = (px0 + x) >> 6;
+            const float* lfp = f.lf[c] + (int64_t)b.cy * f.bw + b.cx;
+            float* dst = img0 + bi * IMG + x;
+            int ty_cached = -1;
+            float kcfl = 0.0f;
+#pragma unroll 4
+            for (int n = r0; n < H; n += RSTEP) {
+                const int64_t off = (int64_t)(py0 + n) * FW + px0 + x;
+                float co;
+                if (n < DSH && x < DSW) {
+                    co = llf_coeff<DSH, DSW>(f, lfp, n, x);
+                } else {
+                    co = dequant1_tab(f.coeff[c][off], qbc, qbn, sfc, wc[n * W + x], qtab);
+                    if (c != 1) {
+                        const int ty = (py0 + n) >> 6;
+                        if (ty != ty_cached) {
+                            float kX, kB;
+                            cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - ty0) * 5 + (tx - tx0))) & 1u, kX, kB);
+                            kcfl = c == 0 ? kX : kB;
+                            ty_cached = ty;
+                        }
+                        const float dy = dequant1_tab(f.coeff[1][off], qby, qbn, sfy, wy[n * W + x], qtab);
+                        co = co + kcfl * dy;
+                    }
+                }
+                dst[n * LD] = co;
+            }
+        }
+    }
+    __syncthreads();
+    // 2. column pass: lanes enumerate (chunk, block, column), x fastest
+    {
+        constexpr int KC = Cfg::KC_COL;
+        const int col = tid % (NBLK * W), kc = __builtin_amdgcn_readfirstlane(tid / (NBLK * W));
+        const int bi = col / W, x = col % W;
+        if (bi < nb) {
+            const float* src = img0 + bi * IMG + x;
+            const float* lut = f.lut + lut_off(ceil_log2_dev(H)) + kc * KC;
+            v2f acc[KC / 2];
+            const float s0 = src[0];
+#pragma unroll
+            for (int k = 0; k < KC / 2; k++) acc[k] = v2f{s0, s0};
+#pragma unroll 4
+            for (int n = 1; n < H; n++) {
+                const float s2 = src[n * LD];
+                const v2f s22 = {s2, s2};
+                const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * H);
+#pragma unroll
+                for (int k = 0; k < KC / 2; k++) acc[k] = acc[k] + s22 * lr[k];
+            }
+            float* d = img1 + bi * IMG + (kc * KC) * LD + x;
+#pragma unroll
+            for (int k = 0; k < KC / 2; k++) {
+                d[(2 * k) * LD] = acc[k].x;
+                d[(2 * k + 1) * LD] = acc[k].y;
+            }
+        }
+    }
+    __syncthreads();
+    // 3. row pass: lanes enumerate (chunk, block, row), y fastest; each lane stores KC consecutive outputs
+    {
+        constexpr int KC = Cfg::KC_ROW;
+        const int rr = tid % (NBLK * H), kc = __builtin_amdgcn_readfirstlane(tid / (NBLK * H));
+        const int bi = rr / H, y = rr % H;
+        if (bi < nb) {
+            const DevBlock b = blocks[it.first + bi];
+            const float* row = img1 + bi * IMG + y * LD;
+            const float* lut = f.lut + lut_off(ceil_log2_dev(W)) + kc * KC;
+            v2f acc[KC / 2];
+            const float s0 = row[0];
+#pragma unroll
+            for (int k = 0; k < KC / 2; k++) acc[k] = v2f{s0, s0};
+#pragma unroll 4
+            for (int n = 1; n < W; n++) {
+                const float s2 = row[n];
+                const v2f s22 = {s2, s2};
+                const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * W);
+#pragma unroll
+                for (int k = 0; k < KC / 2; k++) acc[k] = acc[k] + s22 * lr[k];
+            }
+            float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8 + kc * KC;
+#pragma unroll
+            for (int k = 0; k < KC / 2; k += 2) *reinterpret_cast<float4*>(o + 2 * k) = make_float4(acc[k].x, acc[k].y, acc[k + 1].x, acc[k + 1].y);
+        }
+    }
+}
+
+// ---- launches: one kernel per transform type present ------------------------------------------------------------
+// A single merged kernel (switch on the work item's type) was tried: hipcc allocates such a kernel 256 VGPRs +
+// scratch (code motion across the inlined branches; `amdgpu_num_vgpr` cannot be put on device functions), which
+// leaves one wave per SIMD. Per-type kernels keep their natural 59..150 VGPRs.
+template <int H, int W, int TYPE>
+__global__ __launch_bounds__(256) void k_idct_type(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                   const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
     extern __shared__ float lds[];
-    medium_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
+    if (H == 64 || W == 64) wg64_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
+    else medium_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
 }
+
+size_t medium_lds_bytes(int type);
 
 template <int H, int W, int TYPE>
-static void launch_medium_t(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n, float* const out[3],
-                            hipStream_t s) {
-    constexpr size_t lds_bytes = MediumCfg<H, W>::LDS_BYTES;
-    hipLaunchKernelGGL((k_idct_medium<H, W, TYPE>), dim3(n), dim3(64), lds_bytes, s, f, blocks, items, out[0], out[1], out[2]);
+static void launch_type_t(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n, float* const out[3],
+                          hipStream_t s) {
+    const size_t lds_bytes = medium_lds_bytes(TYPE);
+    hipLaunchKernelGGL((k_idct_type<H, W, TYPE>), dim3(n), dim3(256), lds_bytes, s, f, blocks, items, out[0], out[1], out[2]);
 }
 
-// items: all of ONE type. type 0: up to 64 DCT8 blocks per item (all channels); medium types: up to
-// medium_blocks_per_wg(type) blocks of channel (WorkItem.type >> 8) per item.
+// items: all of ONE type; WorkItem.type = type | channel << 8, up to medium_blocks_per_wg(type) blocks per item
 void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, int type, float* const out[3],
                       hipStream_t s) {
     if (n_items <= 0) return;
     switch (type) {
-    case 0:
-        if (getenv("JXL_DCT8_LANEBLOCK")) hipLaunchKernelGGL(k_idct_dct8, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
-        else launch_medium_t<8, 8, 0>(f, blocks, items, n_items, out, s);
-        break;
-    case 4: launch_medium_t<16, 16, 4>(f, blocks, items, n_items, out, s); break;
-    case 5: launch_medium_t<32, 32, 5>(f, blocks, items, n_items, out, s); break;
-    case 6: launch_medium_t<16, 8, 6>(f, blocks, items, n_items, out, s); break;
-    case 7: launch_medium_t<8, 16, 7>(f, blocks, items, n_items, out, s); break;
-    case 8: launch_medium_t<32, 8, 8>(f, blocks, items, n_items, out, s); break;
-    case 9: launch_medium_t<8, 32, 9>(f, blocks, items, n_items, out, s); break;
-    case 10: launch_medium_t<32, 16, 10>(f, blocks, items, n_items, out, s); break;
-    case 11: launch_medium_t<16, 32, 11>(f, blocks, items, n_items, out, s); break;
-    case 18: launch_medium_t<64, 64, 18>(f, blocks, items, n_items, out, s); break;
-    case 19: launch_medium_t<64, 32, 19>(f, blocks, items, n_items, out, s); break;
-    case 20: launch_medium_t<32, 64, 20>(f, blocks, items, n_items, out, s); break;
+    case 0: launch_type_t<8, 8, 0>(f, blocks, items, n_items, out, s); break;
+    case 4: launch_type_t<16, 16, 4>(f, blocks, items, n_items, out, s); break;
+    case 5: launch_type_t<32, 32, 5>(f, blocks, items, n_items, out, s); break;
+    case 6: launch_type_t<16, 8, 6>(f, blocks, items, n_items, out, s); break;
+    case 7: launch_type_t<8, 16, 7>(f, blocks, items, n_items, out, s); break;
+    case 8: launch_type_t<32, 8, 8>(f, blocks, items, n_items, out, s); break;
+    case 9: launch_type_t<8, 32, 9>(f, blocks, items, n_items, out, s); break;
+    case 10: launch_type_t<32, 16, 10>(f, blocks, items, n_items, out, s); break;
+    case 11: launch_type_t<16, 32, 11>(f, blocks, items, n_items, out, s); break;
+    case 18: launch_type_t<64, 64, 18>(f, blocks, items, n_items, out, s); break;
+    case 19: launch_type_t<64, 32, 19>(f, blocks, items, n_items, out, s); break;
+    case 20: launch_type_t<32, 64, 20>(f, blocks, items, n_items, out, s); break;
     default: break;
     }
+}
+
+// blocks of one channel that one workgroup (work item) handles
+int medium_blocks_per_wg(int type) {
+    const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
+    if (h == 64 || w == 64) return 64 / (h < w ? h : w);
+    return 4 * (64 / (h > w ? h : w));
+}
+
+size_t medium_lds_bytes(int type) {
+    const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
+    if (h == 64 || w == 64) return sizeof(float) * (size_t)(2 * medium_blocks_per_wg(type) * h * (w + 1) + 64);
+    return sizeof(float) * (size_t)(medium_blocks_per_wg(type) * h * (w + 1) + 64);
 }
 
 // the nine special 8x8-footprint types (Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3): whole block in
@@ -738,10 +907,6 @@ void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkIt
     hipLaunchKernelGGL(k_idct_special, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
 }
 
-int medium_blocks_per_wg(int type) {
-    const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
-    return 64 / (h > w ? h : w);
-}
 
 // ---- large: 128/256-edge blocks through a scratch plane ---------------------------------------------
 // phase A: dequant + CfL of every sample -> out planes (used as the coefficient store); grid.y = block
