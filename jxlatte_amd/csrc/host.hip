@@ -229,7 +229,8 @@ jxl_status finalize_tables(jxl_ctx* c) {
     static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
     for (int t : kSpecial)
         for (uint32_t o = 0; o < sm[t].size(); o += 64)
-            items.push_back(WorkItem{(uint32_t)t, first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
+            for (uint32_t ch = 0; ch < 3; ch++)
+                items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
     c->n_special_items = (int)items.size() - c->special_off;
     c->large_first = (int)c->h_blocks.size();
     for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)

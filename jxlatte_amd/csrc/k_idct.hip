@@ -11,17 +11,24 @@
 // separate IEEE f32 operations (-ffp-contract=off), no MFMA (fused, different order).
 //
 // Three kernel families, all type-uniform per workgroup so there is no divergence:
-//   small  : the ten 8x8-footprint types. One LANE per varblock, the whole 8x8x3 block lives in
-//            VGPRs, every LUT / AFV-basis factor is an instruction literal: pure VALU, no LDS.
-//   medium : DCT16..DCT64 and their rectangles. One 256-thread workgroup per batch of blocks,
-//            coefficients staged in LDS (row stride W+1: conflict-free), lane = one column for
-//            the column pass and one row for the row pass, accumulators in VGPRs, LUT rows
-//            arrive through scalar loads (wave-uniform).
-//   large  : 128/256-edge blocks do not fit LDS: dequant -> column pass -> row pass through a
-//            scratch plane, 64x64 register tiles per wave.
+//   special : Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3. One LANE per (varblock, channel), the whole
+//             8x8 block lives in VGPRs, every LUT / AFV-basis factor is an instruction literal.
+//   wave    : DCT8, DCT16 and the 16x8 rectangles. One WAVE = 64/max(H,W) blocks of one channel:
+//             lane = one column, coefficient rows streamed from HBM in order (dequantised on the fly),
+//             accumulators in VGPRs, LUT rows wave-uniform (scalar loads); transpose through a
+//             wave-private LDS image; lane = one row for the row pass. No workgroup barriers needed.
+//   wg      : the 32- and 64-point families. One 256-thread workgroup per 64/min(H,W) blocks of one
+//             channel: dequantised coefficients staged in LDS, every 1-D transform split over the
+//             waves (8 or 16 outputs per lane) so that no lane runs a 2x63x64-instruction chain.
+//   large   : 128/256-edge blocks do not fit LDS: dequant -> column pass -> row pass through a
+//             scratch plane, 64x64 register tiles per wave.
 #include "jxl_internal.h"
 #include "../../include/jxl_tables.h"
 #include <cstdlib>
+
+#ifndef JXL_WG_PATH_MIN
+#define JXL_WG_PATH_MIN 32
+#endif
 
 namespace jxl {
 
@@ -289,50 +296,9 @@ __device__ __forceinline__ void small_row(const DevFrame& f, int c, int y, int64
     if (y == 0) co[0] = lf_c;
 }
 
-// DCT8: rows are streamed through the column pass (its sum runs over n = row index in ascending order, the
-// reference's order), so only the 64 column accumulators stay live; the row pass emits one output row at a
-// time. ~100 VGPRs instead of 350.
-__device__ __forceinline__ void dct8_block(const DevFrame& f, const DevBlock b, float* __restrict__ o0, float* __restrict__ o1,
-                                           float* __restrict__ o2) {
-    const int W = f.width;
-    const int py0 = b.cy * 8, px0 = b.cx * 8;
-    const int64_t base = (int64_t)py0 * W + px0;
-    const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
-    float kX, kB;
-    cfl_factors(f, py0 >> 6, px0 >> 6, b.cfl_zero & 1u, kX, kB);
-    float* outs[3] = {o0, o1, o2};
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-        const float kc = c == 0 ? kX : kB;
-        const float lf_c = f.lf[c][b.cy * f.bw + b.cx];
-        float t[64];  // t[k*8 + x]: column pass result
-#pragma unroll
-        for (int n = 0; n < 8; n++) {
-            float co[8];
-            small_row<0, true>(f, c, n, base, hfm, kc, lf_c, co);
-#pragma unroll
-            for (int x = 0; x < 8; x++) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (n == 0) t[k * 8 + x] = co[x];
-                    else t[k * 8 + x] = t[k * 8 + x] + co[x] * kLut8[n - 1][k];
-                }
-            }
-        }
-        float* o = outs[c] + base;
-#pragma unroll
-        for (int y = 0; y < 8; y++) {
-            float r[8];
-            idct1d_reg<8, 1, 1>(t + y * 8, r);
-            *reinterpret_cast<float4*>(o + (int64_t)y * W) = make_float4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<float4*>(o + (int64_t)y * W + 4) = make_float4(r[4], r[5], r[6], r[7]);
-        }
-    }
-}
-
 // the other nine 8x8-footprint types: whole block of one channel in registers
 template <int TYPE>
-__device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock b, float* __restrict__ o0,
+__device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock b, const int c, float* __restrict__ o0,
                                               float* __restrict__ o1, float* __restrict__ o2) {
     constexpr int PI = TYPE == 1 ? 1 : TYPE == 2 ? 2 : TYPE == 3 ? 3 : (TYPE == 12 || TYPE == 13) ? 9 : 10;
     const int W = f.width;
@@ -341,16 +307,14 @@ __device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock 
     const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
     float kX, kB;
     cfl_factors(f, py0 >> 6, px0 >> 6, b.cfl_zero & 1u, kX, kB);
-    float* outs[3] = {o0, o1, o2};
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
+    {
         const float kc = c == 0 ? kX : kB;
         const float lf_c = f.lf[c][b.cy * f.bw + b.cx];
         float co[64], px[64];
 #pragma unroll
         for (int y = 0; y < 8; y++) small_row<PI, false>(f, c, y, base, hfm, kc, lf_c, co + y * 8);
         invert_small<TYPE>(co, px);
-        float* o = outs[c] + base;
+        float* o = (c == 0 ? o0 : c == 1 ? o1 : o2) + base;
 #pragma unroll
         for (int y = 0; y < 8; y++) {
             *reinterpret_cast<float4*>(o + (int64_t)y * W) = make_float4(px[y * 8], px[y * 8 + 1], px[y * 8 + 2], px[y * 8 + 3]);
@@ -726,44 +690,54 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
     const float qbn = f.quant_bias_numerator;
     if (tid < 64) qtab[tid] = tid > 0 ? qbn / (float)tid : 0.0f;
     __syncthreads();
-    // 1. dequant + CfL + LLF -> img0 (lane = column, rows strided over the workgroup: coalesced rows)
+    // 1. dequant + CfL + LLF -> img0. Sample s = j*256 + tid of the NBLK blocks (x fastest: coalesced rows); all
+    //    global loads of the workgroup's NS sweeps are issued before the arithmetic.
     {
         const float* wc = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + c];
         const float* wy = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + 1];
-        constexpr int RSTEP = 256 / W;  // rows covered per sweep
+        constexpr int RSTEP = 256 / W;          // rows covered per sweep
+        constexpr int BSTEP = (H * W) / 256;    // sweeps per block
+        constexpr int NS = NBLK * BSTEP;        // sweeps per workgroup
         const int x = tid % W, r0 = tid / W;
-        for (int bi = 0; bi < nb; bi++) {
-            const DevBlock b = blocks[it.first + bi];
-            const int py0 = b.cy * 8, px0 = b.cx * 8;
-            const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
-            const float sfc = f.scale_factor[c] / hfm, sfy = f.scale_factor[1] / hfm;
-            const float qbc = f.quant_bias[c], qby = f.quant_bias[1];
-            const int ty0 = py0 >> 6, tx0 = px0 >> 6, tx = (px0 + x) >> 6;
-            const float* lfp = f.lf[c] + (int64_t)b.cy * f.bw + b.cx;
-            float* dst = img0 + bi * IMG + x;
-            int ty_cached = -1;
-            float kcfl = 0.0f;
-#pragma unroll 4
-            for (int n = r0; n < H; n += RSTEP) {
-                const int64_t off = (int64_t)(py0 + n) * FW + px0 + x;
+        int qcv[NS], qyv[NS];
+        float wcv[NS], wyv[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int bi = j / BSTEP, n = (j % BSTEP) * RSTEP + r0;
+            qcv[j] = qyv[j] = 0;
+            wcv[j] = wyv[j] = 0.0f;
+            if (bi < nb) {
+                const DevBlock b = blocks[it.first + bi];
+                const int64_t off = (int64_t)(b.cy * 8 + n) * FW + b.cx * 8 + x;
+                qcv[j] = f.coeff[c][off];
+                wcv[j] = wc[n * W + x];
+                if (c != 1) {
+                    qyv[j] = f.coeff[1][off];
+                    wyv[j] = wy[n * W + x];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int bi = j / BSTEP, n = (j % BSTEP) * RSTEP + r0;
+            if (bi < nb) {
+                const DevBlock b = blocks[it.first + bi];
+                const int py0 = b.cy * 8, px0 = b.cx * 8;
+                const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
                 float co;
                 if (n < DSH && x < DSW) {
-                    co = llf_coeff<DSH, DSW>(f, lfp, n, x);
+                    co = llf_coeff<DSH, DSW>(f, f.lf[c] + (int64_t)b.cy * f.bw + b.cx, n, x);
                 } else {
-                    co = dequant1_tab(f.coeff[c][off], qbc, qbn, sfc, wc[n * W + x], qtab);
+                    co = dequant1_tab(qcv[j], f.quant_bias[c], qbn, f.scale_factor[c] / hfm, wcv[j], qtab);
                     if (c != 1) {
-                        const int ty = (py0 + n) >> 6;
-                        if (ty != ty_cached) {
-                            float kX, kB;
-                            cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - ty0) * 5 + (tx - tx0))) & 1u, kX, kB);
-                            kcfl = c == 0 ? kX : kB;
-                            ty_cached = ty;
-                        }
-                        const float dy = dequant1_tab(f.coeff[1][off], qby, qbn, sfy, wy[n * W + x], qtab);
-                        co = co + kcfl * dy;
+                        const int ty = (py0 + n) >> 6, tx = (px0 + x) >> 6;
+                        float kX, kB;
+                        cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - (py0 >> 6)) * 5 + (tx - (px0 >> 6)))) & 1u, kX, kB);
+                        const float dy = dequant1_tab(qyv[j], f.quant_bias[1], qbn, f.scale_factor[1] / hfm, wyv[j], qtab);
+                        co = co + (c == 0 ? kX : kB) * dy;
                     }
                 }
-                dst[n * LD] = co;
+                img0[bi * IMG + n * LD + x] = co;
             }
         }
     }
@@ -825,6 +799,9 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
     }
 }
 
+// which types take the workgroup-level (LDS-staged, k-split) path instead of the wave-level streamed one
+__host__ __device__ constexpr bool use_wg_path(int h, int w) { return (h > w ? h : w) >= JXL_WG_PATH_MIN; }
+
 // ---- launches: one kernel per transform type present ------------------------------------------------------------
 // A single merged kernel (switch on the work item's type) was tried: hipcc allocates such a kernel 256 VGPRs +
 // scratch (code motion across the inlined branches; `amdgpu_num_vgpr` cannot be put on device functions), which
@@ -833,7 +810,7 @@ template <int H, int W, int TYPE>
 __global__ __launch_bounds__(256) void k_idct_type(const DevFrame f, const DevBlock* __restrict__ blocks,
                                                    const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
     extern __shared__ float lds[];
-    if (H == 64 || W == 64) wg64_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
+    if constexpr (use_wg_path(H, W)) wg64_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
     else medium_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
 }
 
@@ -870,13 +847,13 @@ void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem*
 // blocks of one channel that one workgroup (work item) handles
 int medium_blocks_per_wg(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
-    if (h == 64 || w == 64) return 64 / (h < w ? h : w);
+    if (use_wg_path(h, w)) return 64 / (h < w ? h : w);
     return 4 * (64 / (h > w ? h : w));
 }
 
 size_t medium_lds_bytes(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
-    if (h == 64 || w == 64) return sizeof(float) * (size_t)(2 * medium_blocks_per_wg(type) * h * (w + 1) + 64);
+    if (use_wg_path(h, w)) return sizeof(float) * (size_t)(2 * medium_blocks_per_wg(type) * h * (w + 1) + 64);
     return sizeof(float) * (size_t)(medium_blocks_per_wg(type) * h * (w + 1) + 64);
 }
 
@@ -887,16 +864,17 @@ __global__ __launch_bounds__(64) void k_idct_special(const DevFrame f, const Dev
     const WorkItem it = items[blockIdx.x];
     if (threadIdx.x >= it.count) return;
     const DevBlock b = blocks[it.first + threadIdx.x];
+    const int c = (int)(it.type >> 8);  // one channel per item: 3x the waves, a third of the latency
     switch (it.type & 0xffu) {
-    case 1: special_block<1>(f, b, o0, o1, o2); break;
-    case 2: special_block<2>(f, b, o0, o1, o2); break;
-    case 3: special_block<3>(f, b, o0, o1, o2); break;
-    case 12: special_block<12>(f, b, o0, o1, o2); break;
-    case 13: special_block<13>(f, b, o0, o1, o2); break;
-    case 14: special_block<14>(f, b, o0, o1, o2); break;
-    case 15: special_block<15>(f, b, o0, o1, o2); break;
-    case 16: special_block<16>(f, b, o0, o1, o2); break;
-    case 17: special_block<17>(f, b, o0, o1, o2); break;
+    case 1: special_block<1>(f, b, c, o0, o1, o2); break;
+    case 2: special_block<2>(f, b, c, o0, o1, o2); break;
+    case 3: special_block<3>(f, b, c, o0, o1, o2); break;
+    case 12: special_block<12>(f, b, c, o0, o1, o2); break;
+    case 13: special_block<13>(f, b, c, o0, o1, o2); break;
+    case 14: special_block<14>(f, b, c, o0, o1, o2); break;
+    case 15: special_block<15>(f, b, c, o0, o1, o2); break;
+    case 16: special_block<16>(f, b, c, o0, o1, o2); break;
+    case 17: special_block<17>(f, b, c, o0, o1, o2); break;
     default: break;
     }
 }
