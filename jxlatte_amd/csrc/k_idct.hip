@@ -808,10 +808,14 @@ __host__ __device__ constexpr bool use_wg_path(int h, int w) { return (h > w ? h
 // leaves one wave per SIMD. Per-type kernels keep their natural 59..150 VGPRs.
 template <int H, int W, int TYPE>
 __global__ __launch_bounds__(256) void k_idct_type(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                   const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+                                                   const WorkItem* __restrict__ items, int n_items, float* o0, float* o1, float* o2) {
     extern __shared__ float lds[];
-    if constexpr (use_wg_path(H, W)) wg64_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
-    else medium_item<H, W, TYPE>(f, blocks, items[blockIdx.x], lds, o0, o1, o2);
+    // XCD-aware item order (see k_restore_fused): each XCD takes a contiguous run of the spatially ordered items
+    const int per_xcd = (n_items + 7) >> 3;
+    const int idx = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (idx >= n_items) return;
+    if constexpr (use_wg_path(H, W)) wg64_item<H, W, TYPE>(f, blocks, items[idx], lds, o0, o1, o2);
+    else medium_item<H, W, TYPE>(f, blocks, items[idx], lds, o0, o1, o2);
 }
 
 size_t medium_lds_bytes(int type);
@@ -820,7 +824,7 @@ template <int H, int W, int TYPE>
 static void launch_type_t(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n, float* const out[3],
                           hipStream_t s) {
     const size_t lds_bytes = medium_lds_bytes(TYPE);
-    hipLaunchKernelGGL((k_idct_type<H, W, TYPE>), dim3(n), dim3(256), lds_bytes, s, f, blocks, items, out[0], out[1], out[2]);
+    hipLaunchKernelGGL((k_idct_type<H, W, TYPE>), dim3(((n + 7) / 8) * 8), dim3(256), lds_bytes, s, f, blocks, items, n, out[0], out[1], out[2]);
 }
 
 // items: all of ONE type; WorkItem.type = type | channel << 8, up to medium_blocks_per_wg(type) blocks per item
