@@ -95,7 +95,8 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
 #pragma unroll
         for (int t = 0; t < NT; t++) dist[i][t] = 0.0f;
 
-#pragma unroll
+    // channels one after the other (not interleaved by the scheduler): keeps the live set under 128 VGPRs
+#pragma unroll 1
     for (int c = 0; c < 3; c++) {
         // neighbourhood of this channel in registers; only the diamond of radius R around the patch is
         // ever referenced, the compiler drops the unused corner loads
@@ -203,18 +204,21 @@ __device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* 
         float res[3][4 * PH];
         epf_patch<ITER, SW, PLANE, PH>(src, ry, rx, s_inv, border, ep, res);
 #pragma unroll
-        for (int py = 0; py < PH; py++)
+        for (int py = 0; py < PH; py++) {
+            const int y = ry + py;
+            if (LAST) {
+                if (y < G::IH - m) sink.row4(y, rx, &res[0][py * 4], &res[1][py * 4], &res[2][py * 4], min(4, G::IW - m - rx));
+            } else {
 #pragma unroll
-            for (int px = 0; px < 4; px++) {
-                const int y = ry + py, x = rx + px;
-                if (y < G::IH - m && x < G::IW - m) {
-                    if (LAST) sink(y, x, res[0][py * 4 + px], res[1][py * 4 + px], res[2][py * 4 + px]);
-                    else {
+                for (int px = 0; px < 4; px++) {
+                    const int x = rx + px;
+                    if (y < G::IH - m && x < G::IW - m) {
 #pragma unroll
                         for (int c = 0; c < 3; c++) dst[c * PLANE + y * SW + x] = res[c][py * 4 + px];
                     }
                 }
             }
+        }
     }
 }
 
@@ -245,6 +249,92 @@ struct FusedArgs {
     const int32_t* sharpness;
     int W, H, bw;
     RestoreParams p;
+};
+
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(8))) f4a8 {
+    float x, y, z, w;
+};
+
+// OpsinInverseMatrix.invertXYB + JXLImage.transferInPlace + ImageBuffer.castToInt0 + the global store
+template <bool PLAIN>
+struct OutSink {
+    const FusedArgs& a;
+    const TileCtx& tc;
+    __device__ __forceinline__ void colour(float& v0, float& v1, float& v2) const {
+        if (a.p.xyb) {
+            const XybParams& xp = a.p.xybp;
+            const float gammaL = v1 + v0 + xp.cob[0];
+            const float gammaM = v1 - v0 + xp.cob[1];
+            const float gammaS = v2 + xp.cob[2];
+            const float mixL = (gammaL * gammaL) * gammaL + xp.ob[0];
+            const float mixM = (gammaM * gammaM) * gammaM + xp.ob[1];
+            const float mixS = (gammaS * gammaS) * gammaS + xp.ob[2];
+            v0 = xp.sm[0] * mixL + xp.sm[1] * mixM + xp.sm[2] * mixS;
+            v1 = xp.sm[3] * mixL + xp.sm[4] * mixM + xp.sm[5] * mixS;
+            v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
+        }
+    }
+    __device__ __forceinline__ void store1(uint32_t g, float v0, float v1, float v2) const {
+        float v[3] = {v0, v1, v2};
+        if (PLAIN) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
+            return;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float t = v[c];
+            if (a.p.transfer == JXL_TRANSFER_PQ) t = tf_pq_f(t);
+            else if (a.p.transfer == JXL_TRANSFER_SRGB) t = tf_srgb_f(t);
+            if (a.p.max_value > 0) {
+                int32_t q = f2i_java(t * (float)a.p.max_value + 0.5f);
+                q = q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
+                if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+                else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
+                else ((int32_t*)a.out[c])[g] = q;
+            } else {
+                ((float*)a.out[c])[g] = t;
+            }
+        }
+    }
+    // one pixel at region position (y, x)
+    __device__ __forceinline__ void operator()(int y, int x, float v0, float v1, float v2) const {
+        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
+        if (gy >= tc.H || gx >= tc.W) return;
+        colour(v0, v1, v2);
+        store1((uint32_t)(gy * tc.W + gx), v0, v1, v2);
+    }
+    // up to 4 consecutive pixels of a row (a patch row); float planes leave as 8-byte stores when aligned
+    __device__ __forceinline__ void row4(int y, int x, const float* r0, const float* r1, const float* r2, int nvalid) const {
+        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
+        if (gy >= tc.H) return;
+        const int n = min(nvalid, tc.W - gx);
+        if (n <= 0) return;
+        float o[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o[0][i] = r0[i];
+            o[1][i] = r1[i];
+            o[2][i] = r2[i];
+            colour(o[0][i], o[1][i], o[2][i]);
+        }
+        const uint32_t g = (uint32_t)(gy * tc.W + gx);
+        if (PLAIN && n == 4 && (g & 1u) == 0) {
+            // one 16-byte store per lane and channel: a wave instruction then covers whole rows of 256 contiguous
+            // bytes instead of every other 8 bytes (tile origins are multiples of 62 px: 8-byte aligned, so the
+            // store is declared 8-byte aligned; gfx950 global stores do not need 16-byte alignment)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                f4a8* d = reinterpret_cast<f4a8*>((float*)a.out[c] + g);
+                *d = f4a8{o[c][0], o[c][1], o[c][2], o[c][3]};
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < n) store1(g + i, o[0][i], o[1][i], o[2][i]);
+    }
 };
 
 // PLAIN = true: float planes out, no transfer function (keeps the double-precision pow() code of the
@@ -350,44 +440,7 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
     }
 
     // final sink: XYB + transfer/quantise + global store
-    auto sink = [&](int y, int x, float v0, float v1, float v2) {
-        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
-        if (gy >= H || gx >= W) return;
-        if (a.p.xyb) {
-            const XybParams& xp = a.p.xybp;
-            const float gammaL = v1 + v0 + xp.cob[0];
-            const float gammaM = v1 - v0 + xp.cob[1];
-            const float gammaS = v2 + xp.cob[2];
-            const float mixL = (gammaL * gammaL) * gammaL + xp.ob[0];
-            const float mixM = (gammaM * gammaM) * gammaM + xp.ob[1];
-            const float mixS = (gammaS * gammaS) * gammaS + xp.ob[2];
-            v0 = xp.sm[0] * mixL + xp.sm[1] * mixM + xp.sm[2] * mixS;
-            v1 = xp.sm[3] * mixL + xp.sm[4] * mixM + xp.sm[5] * mixS;
-            v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
-        }
-        const uint32_t g = (uint32_t)(gy * W + gx);
-        float v[3] = {v0, v1, v2};
-        if (PLAIN) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
-            return;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float t = v[c];
-            if (a.p.transfer == JXL_TRANSFER_PQ) t = tf_pq_f(t);
-            else if (a.p.transfer == JXL_TRANSFER_SRGB) t = tf_srgb_f(t);
-            if (a.p.max_value > 0) {
-                int32_t q = f2i_java(t * (float)a.p.max_value + 0.5f);
-                q = q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
-                if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
-                else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
-                else ((int32_t*)a.out[c])[g] = q;
-            } else {
-                ((float*)a.out[c])[g] = t;
-            }
-        }
-    };
+    const OutSink<PLAIN> sink{a, tc};
 
     if (ITERS == 0) {
         const int mm = m;
