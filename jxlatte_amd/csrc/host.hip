@@ -39,7 +39,8 @@ struct DevBuf {
 };
 
 struct ModOp {
-    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy
+    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy, 4 batched squeeze step (bt)
+    SqueezeBatch bt;
     const int32_t* a;
     const int32_t* b;
     int32_t* o;
@@ -1076,6 +1077,10 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
         const int offset = sp[j].in_place ? end + 1 : n + begin - end - 1;
         if (begin < 0 || end < begin || end >= n || offset < 0 || offset + (end - begin) >= n)
             return fail(c, JXL_ERR_INVALID_BITSTREAM, "squeeze step %d addresses channels outside the list", j);
+        ModOp batch{};
+        batch.kind = 4;
+        batch.bt.n = 0;
+        batch.bt.horizontal = sp[j].horizontal ? 1 : 0;
         for (int k = begin; k <= end; k++) {
             const int r = offset + k - begin;
             const ModChan a = ch[k], re = ch[r];
@@ -1094,9 +1099,14 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
             if (!o.d) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze output)");
             o.original = false;
             op.a = a.d; op.b = re.d; op.o = o.d;
-            c->mod_ops.push_back(op);
+            batch.bt.d[batch.bt.n++] = SqueezeDesc{a.d, re.d, o.d, op.adim, op.rdim, op.other};
+            if (batch.bt.n == 8) {
+                c->mod_ops.push_back(batch);
+                batch.bt.n = 0;
+            }
             ch[k] = o;
         }
+        if (batch.bt.n > 0) c->mod_ops.push_back(batch);
         ch.erase(ch.begin() + offset, ch.begin() + offset + (end - begin + 1));
     }
     if (rct_type >= 0) {  // RCT branch (:255-326)
@@ -1137,6 +1147,7 @@ jxl_status jxl_modular_run(jxl_ctx* c) {
         case 1: launch_inv_vsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, c->stream); break;
         case 2: launch_rct(op.v0, op.v1, op.v2, op.n, op.type, c->stream); break;
         case 3: (void)hipMemcpyAsync(op.o, op.a, 4 * (size_t)op.n, hipMemcpyDeviceToDevice, c->stream); break;
+        case 4: launch_squeeze_batch(op.bt, c->stream); break;
         }
         launches++;
     }

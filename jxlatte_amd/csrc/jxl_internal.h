@@ -111,6 +111,20 @@ struct RestoreParams {
 bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                           const int32_t* sharpness, const RestoreParams& p, hipStream_t s);
 
+// one inverse squeeze step over up to 8 channels in a single launch
+struct SqueezeDesc {
+    const int32_t* a;  // averages
+    const int32_t* b;  // residuals
+    int32_t* o;        // output
+    int adim, rdim;    // squeezed-axis length of a and b (widths for H, heights for V)
+    int other;         // the other dimension (rows for H, columns for V)
+};
+struct SqueezeBatch {
+    int n;
+    int horizontal;
+    SqueezeDesc d[8];
+};
+void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s);
 void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out, hipStream_t s);
 void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh, int w, int32_t* out, hipStream_t s);
 void launch_rct(int32_t* v0, int32_t* v1, int32_t* v2, int64_t n, int type, hipStream_t s);

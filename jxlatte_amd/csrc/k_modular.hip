@@ -20,89 +20,222 @@ __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 
-// ModularChannel.tendency (ModularChannel.java:23-47)
-__device__ __forceinline__ int32_t tendency(int32_t a, int32_t b, int32_t c) {
-    if (a >= b && b >= c) {
-        int32_t x = wadd(wsub(wsub(wmul(4, a), wmul(3, c)), b), 6) / 12;
-        const int32_t d = wmul(2, wsub(a, b));
-        const int32_t e = wmul(2, wsub(b, c));
-        if (wsub(x, (x & 1)) > d) x = wadd(d, 1);
-        if (wadd(x, (x & 1)) > e) x = e;
-        return x;
-    }
-    if (a <= b && b <= c) {
-        int32_t x = wsub(wsub(wsub(wmul(4, a), wmul(3, c)), b), 6) / 12;
-        const int32_t d = wmul(2, wsub(a, b));
-        const int32_t e = wmul(2, wsub(b, c));
-        if (wadd(x, (x & 1)) < d) x = wsub(d, 1);
-        if (wsub(x, (x & 1)) < e) x = e;
-        return x;
-    }
-    return 0;
+// ModularChannel.tendency (ModularChannel.java:23-47), branch-free and split so that only the part that depends on
+// `a` (the previously OUTPUT sample: the serial dependency of the squeeze recurrence) sits on the critical path.
+// Everything derived from b and c alone is prepared ahead (TendPre). int32 wrap-around is kept everywhere, so the
+// result equals the reference also for samples near INT_MIN / INT_MAX.
+struct TendPre {
+    int32_t base;  // -3c - b
+    int32_t e;     // 2 (b - c)
+    int32_t twob;  // 2 b
+    int32_t b;
+    bool ge, le;   // b >= c, b <= c
+};
+
+__device__ __forceinline__ TendPre tend_pre(int32_t b, int32_t c) {
+    TendPre t;
+    t.base = wsub(wmul(-3, c), b);
+    t.e = wmul(2, wsub(b, c));
+    t.twob = wmul(2, b);
+    t.b = b;
+    t.ge = b >= c;
+    t.le = b <= c;
+    return t;
 }
 
-// inverseVerticalSqueeze (ModularChannel.java:389-413): lane = column
-__global__ __launch_bounds__(64) void k_inv_vsqueeze(const int32_t* __restrict__ avg, int ah, const int32_t* __restrict__ res,
-                                                     int rh, int w, int32_t* __restrict__ out) {
+__device__ __forceinline__ int32_t tend_apply(int32_t a, const TendPre& t) {
+    const bool dec = t.ge && a >= t.b;           // if (a >= b && b >= c)
+    const bool inc = !dec && t.le && a <= t.b;   // else if (a <= b && b <= c)
+    const int32_t x = wadd(wadd(wmul(4, a), t.base), dec ? 6 : -6) / 12;
+    const int32_t d = wsub(wmul(2, a), t.twob);
+    // decreasing: if (x - (x&1) > d) x = d + 1; if (x + (x&1) > e) x = e;
+    int32_t xd = x;
+    xd = wsub(xd, xd & 1) > d ? wadd(d, 1) : xd;
+    xd = wadd(xd, xd & 1) > t.e ? t.e : xd;
+    // increasing: if (x + (x&1) < d) x = d - 1; if (x - (x&1) < e) x = e;
+    int32_t xi = x;
+    xi = wadd(xi, xi & 1) < d ? wsub(d, 1) : xi;
+    xi = wsub(xi, xi & 1) < t.e ? t.e : xi;
+    return dec ? xd : (inc ? xi : 0);
+}
+
+__device__ __forceinline__ int32_t tendency(int32_t a, int32_t b, int32_t c) { return tend_apply(a, tend_pre(b, c)); }
+
+// One squeeze step is ONE launch over all of its channels: blockIdx.y selects the channel descriptor.
+// (SqueezeBatch is declared in jxl_internal.h.)
+
+// inverseVerticalSqueeze (ModularChannel.java:389-413): lane = column. The avg/res rows do not depend on the
+// recurrence, so they are fetched RV rows ahead (all loads of a chunk in flight) and only the short
+// left -> tendency -> diff -> first/second chain is serial.
+__global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
+    const SqueezeDesc d = bt.d[blockIdx.y];
+    const int w = d.other, ah = d.adim, rh = d.rdim;
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
+    const int32_t* __restrict__ avg = d.a;
+    const int32_t* __restrict__ res = d.b;
+    int32_t* __restrict__ out = d.o;
+    constexpr int RV = 8;
     int32_t top = 0;
     int32_t a = rh > 0 ? avg[x] : 0;
-    for (int y = 0; y < rh; y++) {
-        const int32_t residu = res[(int64_t)y * w + x];
-        const int32_t nextAvg = y + 1 < ah ? avg[(int64_t)(y + 1) * w + x] : a;
-        const int32_t t = y > 0 ? top : a;
-        const int32_t diff = wadd(residu, tendency(t, a, nextAvg));
-        const int32_t first = wadd(a, diff / 2);
-        const int32_t second = wsub(first, diff);
-        out[(int64_t)(2 * y) * w + x] = first;
-        out[(int64_t)(2 * y + 1) * w + x] = second;
-        top = second;
-        a = nextAvg;
+    for (int y0 = 0; y0 < rh; y0 += RV) {
+        int32_t rr[RV], na[RV];
+#pragma unroll
+        for (int i = 0; i < RV; i++) {
+            const int y = y0 + i;
+            rr[i] = y < rh ? res[(int64_t)y * w + x] : 0;
+            na[i] = (y < rh && y + 1 < ah) ? avg[(int64_t)(y + 1) * w + x] : 0;
+        }
+        // everything that does not depend on the recurrence first
+        int32_t av[RV + 1];
+        TendPre tp[RV];
+        av[0] = a;
+#pragma unroll
+        for (int i = 0; i < RV; i++) {
+            const int y = y0 + i;
+            av[i + 1] = y + 1 < ah ? na[i] : av[i];
+            tp[i] = tend_pre(av[i], av[i + 1]);
+        }
+        if (y0 + RV <= rh) {  // full chunk: no guards on the serial chain, stores after it
+            int32_t o1[RV], o2[RV];
+#pragma unroll
+            for (int i = 0; i < RV; i++) {
+                const int32_t t = (y0 + i) > 0 ? top : av[i];
+                const int32_t diff = wadd(rr[i], tend_apply(t, tp[i]));
+                o1[i] = wadd(av[i], diff / 2);
+                o2[i] = wsub(o1[i], diff);
+                top = o2[i];
+            }
+#pragma unroll
+            for (int i = 0; i < RV; i++) {
+                out[(int64_t)(2 * (y0 + i)) * w + x] = o1[i];
+                out[(int64_t)(2 * (y0 + i) + 1) * w + x] = o2[i];
+            }
+            a = av[RV];
+        } else {
+#pragma unroll
+            for (int i = 0; i < RV; i++) {
+                const int y = y0 + i;
+                if (y < rh) {
+                    const int32_t t = y > 0 ? top : av[i];
+                    const int32_t diff = wadd(rr[i], tend_apply(t, tp[i]));
+                    const int32_t first = wadd(av[i], diff / 2);
+                    const int32_t second = wsub(first, diff);
+                    out[(int64_t)(2 * y) * w + x] = first;
+                    out[(int64_t)(2 * y + 1) * w + x] = second;
+                    top = second;
+                    a = av[i + 1];
+                }
+            }
+        }
     }
     if (ah > rh) out[(int64_t)(2 * rh) * w + x] = avg[(int64_t)rh * w + x];
 }
 
-// inverseHorizontalSqueeze (ModularChannel.java:361-387): lane = row, LDS-staged 64x64 chunks
-__global__ __launch_bounds__(64) void k_inv_hsqueeze(const int32_t* __restrict__ avg, int aw, const int32_t* __restrict__ res,
-                                                     int rw, int h, int32_t* __restrict__ out) {
+// inverseHorizontalSqueeze (ModularChannel.java:361-387): lane = row. 64-row x 64-column chunks of avg/res are
+// staged through LDS (global traffic stays row-contiguous, the whole chunk's loads are issued before the first
+// LDS write); each lane then walks its own row, four columns per step with the LDS reads hoisted ahead of the
+// serial chain; outputs overwrite the consumed inputs in LDS and leave as contiguous rows.
+__global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
+    const SqueezeDesc d = bt.d[blockIdx.y];
+    const int aw = d.adim, rw = d.rdim, h = d.other;
+    const int y0 = blockIdx.x * 64;
+    if (y0 >= h) return;
+    const int32_t* __restrict__ avg = d.a;
+    const int32_t* __restrict__ res = d.b;
+    int32_t* __restrict__ out = d.o;
     __shared__ int32_t sA[64 * 65];  // avg chunk [row][col]; overwritten in place by the even outputs
     __shared__ int32_t sR[64 * 65];  // res chunk [row][col]; overwritten in place by the odd outputs
     const int lane = threadIdx.x;
-    const int y0 = blockIdx.x * 64;
     const int rows = min(64, h - y0);
     const int ow = aw + rw;
     int32_t left = 0;
-    int32_t a_next_chunk = 0;  // avg[x0 + 64] look-ahead of the lane's own row
     for (int x0 = 0; x0 < rw; x0 += 64) {
         const int cols = min(64, rw - x0);
         __syncthreads();
-        for (int r = 0; r < rows; r++) {
-            if (lane < cols) {
-                sA[r * 65 + lane] = avg[(int64_t)(y0 + r) * aw + x0 + lane];
-                sR[r * 65 + lane] = res[(int64_t)(y0 + r) * rw + x0 + lane];
+        if (rows == 64 && cols == 64) {  // fast path: all 128 row loads in flight, then the LDS writes
+            int32_t ta[64], tr[64];
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                ta[r] = avg[(int64_t)(y0 + r) * aw + x0 + lane];
+                tr[r] = res[(int64_t)(y0 + r) * rw + x0 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                sA[r * 65 + lane] = ta[r];
+                sR[r * 65 + lane] = tr[r];
+            }
+        } else {
+            for (int r = 0; r < rows; r++) {
+                if (lane < cols) {
+                    sA[r * 65 + lane] = avg[(int64_t)(y0 + r) * aw + x0 + lane];
+                    sR[r * 65 + lane] = res[(int64_t)(y0 + r) * rw + x0 + lane];
+                }
             }
         }
         __syncthreads();
         if (lane < rows) {
             const int64_t rowA = (int64_t)(y0 + lane) * aw;
-            // avg[x0 + cols] (first avg of the next chunk, or the odd tail) if it exists
-            const bool has_next = x0 + cols < aw;
-            a_next_chunk = has_next ? avg[rowA + x0 + cols] : 0;
-            for (int i = 0; i < cols; i++) {
-                const int x = x0 + i;
-                const int32_t a = sA[lane * 65 + i];
-                const int32_t residu = sR[lane * 65 + i];
-                int32_t nextAvg;
-                if (i + 1 < cols) nextAvg = sA[lane * 65 + i + 1];
-                else nextAvg = has_next ? a_next_chunk : a;  // x + 1 < orig.width ? orig[x+1] : avg
-                const int32_t l = x > 0 ? left : a;
-                const int32_t diff = wadd(residu, tendency(l, a, nextAvg));
-                const int32_t first = wadd(a, diff / 2);
-                const int32_t second = wsub(first, diff);
-                sA[lane * 65 + i] = first;   // a, residu of column i are consumed; column i+1 is still intact
-                sR[lane * 65 + i] = second;
-                left = second;
+            const bool has_next = x0 + cols < aw;  // avg[x0 + cols]: first avg of the next chunk or the odd tail
+            const int32_t a_next_chunk = has_next ? avg[rowA + x0 + cols] : 0;
+            int32_t* pa = sA + lane * 65;
+            int32_t* pr = sR + lane * 65;
+            constexpr int U = 8;  // columns per step: LDS reads and the a-independent part of tendency() run ahead
+            if (cols == 64) {
+                // full chunk: straight-line code, no per-column guards on the serial chain
+                for (int i0 = 0; i0 < 64; i0 += U) {
+                    int32_t va[U + 1], vr[U];
+                    TendPre tp[U];
+#pragma unroll
+                    for (int j = 0; j <= U; j++) va[j] = pa[i0 + j];  // column 64 of the padded row is scratch
+#pragma unroll
+                    for (int j = 0; j < U; j++) vr[j] = pr[i0 + j];
+                    if (i0 + U == 64) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
+#pragma unroll
+                    for (int j = 0; j < U; j++) tp[j] = tend_pre(va[j], va[j + 1]);
+                    int32_t o1[U], o2[U];
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int32_t l = (x0 + i0 + j) > 0 ? left : va[j];
+                        const int32_t diff = wadd(vr[j], tend_apply(l, tp[j]));
+                        o1[j] = wadd(va[j], diff / 2);
+                        o2[j] = wsub(o1[j], diff);
+                        left = o2[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        pa[i0 + j] = o1[j];  // a, residu of these columns are consumed; the next ones are read afterwards
+                        pr[i0 + j] = o2[j];
+                    }
+                }
+            } else {
+                for (int i0 = 0; i0 < cols; i0 += U) {
+                    int32_t va[U + 1], vr[U];
+                    TendPre tp[U];
+#pragma unroll
+                    for (int j = 0; j <= U; j++) va[j] = pa[min(i0 + j, 64)];
+#pragma unroll
+                    for (int j = 0; j < U; j++) vr[j] = pr[min(i0 + j, 63)];
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int i = i0 + j;
+                        if (i + 1 >= cols) va[j + 1] = has_next ? a_next_chunk : va[j];
+                        tp[j] = tend_pre(va[j], va[j + 1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const int i = i0 + j;
+                        const int32_t l = (x0 + i) > 0 ? left : va[j];
+                        const int32_t diff = wadd(vr[j], tend_apply(l, tp[j]));
+                        const int32_t first = wadd(va[j], diff / 2);
+                        const int32_t second = wsub(first, diff);
+                        if (i < cols) {
+                            pa[i] = first;
+                            pr[i] = second;
+                            left = second;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -116,14 +249,32 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const int32_t* __restrict__
     if (aw > rw && lane < rows) out[(int64_t)(y0 + lane) * ow + 2 * rw] = avg[(int64_t)(y0 + lane) * aw + rw];
 }
 
+void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s) {
+    if (bt.n <= 0) return;
+    int maxdim = 0;
+    for (int i = 0; i < bt.n; i++) maxdim = bt.d[i].other > maxdim ? bt.d[i].other : maxdim;
+    if (maxdim <= 0) return;
+    const dim3 grid((maxdim + 63) / 64, bt.n);
+    if (bt.horizontal) hipLaunchKernelGGL(k_inv_hsqueeze, grid, dim3(64), 0, s, bt);
+    else hipLaunchKernelGGL(k_inv_vsqueeze, grid, dim3(64), 0, s, bt);
+}
+
 void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out, hipStream_t s) {
     if (h <= 0 || aw + rw <= 0) return;
-    hipLaunchKernelGGL(k_inv_hsqueeze, dim3((h + 63) / 64), dim3(64), 0, s, avg, aw, res, rw, h, out);
+    SqueezeBatch bt{};
+    bt.n = 1;
+    bt.horizontal = 1;
+    bt.d[0] = SqueezeDesc{avg, res, out, aw, rw, h};
+    launch_squeeze_batch(bt, s);
 }
 
 void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh, int w, int32_t* out, hipStream_t s) {
     if (w <= 0 || ah + rh <= 0) return;
-    hipLaunchKernelGGL(k_inv_vsqueeze, dim3((w + 63) / 64), dim3(64), 0, s, avg, ah, res, rh, w, out);
+    SqueezeBatch bt{};
+    bt.n = 1;
+    bt.horizontal = 0;
+    bt.d[0] = SqueezeDesc{avg, res, out, ah, rh, w};
+    launch_squeeze_batch(bt, s);
 }
 
 // ModularStream.java:270-324; the channel permutation (:325-326) is applied by the host as pointer shuffling
