@@ -152,6 +152,22 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* ctx, const jxl_vardct_params* params)
  * matrixHeight x matrixWidth row-major; offs[p*3+c] = element offset of set p channel c in w. */
 jxl_status jxl_vardct_set_weights(jxl_ctx* ctx, const float* w, size_t n_floats, const int32_t* offs /*[51]*/);
 jxl_status jxl_vardct_set_lfgroup(jxl_ctx* ctx, const jxl_lfgroup_desc* lfg);
+/* Row f1 (LF stage on device): instead of lfg->lf[] (already dequantised), hand over the INTEGER LF image of the LF
+ * group and let the device run LFCoefficients.java:65-75 (dequant), :78-95 (LF chroma-from-luma) and :113-180
+ * (adaptiveSmooth). Call after jxl_vardct_set_lfgroup for the same LF group (its lf[] pointers may then be NULL).
+ * lf_quant[i]: lfQuant[cMap[i]] i.e. already in X,Y,B buffer order, [cells_h][cells_w] int32;
+ * scaled_dequant = LFGlobal.scaledDequant (X,Y,B); x/b_factor_lf = LFChannelCorrelation.xFactorLF/bFactorLF. */
+typedef struct jxl_lfquant_desc {
+    int32_t lfg_y, lfg_x;
+    int32_t cells_h, cells_w;
+    const int32_t* lf_quant[3];
+    int32_t extra_precision;     /* reader.readBits(2), LFCoefficients.java:61 */
+    float scaled_dequant[3];
+    int32_t x_factor_lf, b_factor_lf;
+    int32_t adaptive_smoothing;  /* (flags & (SKIP_ADAPTIVE_LF_SMOOTHING | USE_LF_FRAME)) == 0 */
+} jxl_lfquant_desc;
+jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* ctx, const jxl_lfquant_desc* d);
+
 /* quantizedCoeffs of one (pass, group) (HFCoefficients.java:43,68): q[c] is [gh][gw] with row
  * stride[c] elements; gh,gw = Frame.getGroupSize(group). pass > 0 accumulates
  * (PassGroup.java:174-200). */
@@ -198,6 +214,10 @@ jxl_status jxl_stage_epf(jxl_ctx* ctx, const float* const in[3], float* const ou
 jxl_status jxl_stage_epf_sigma(jxl_ctx* ctx, const int32_t* hf_mul, const int32_t* sharpness,
                                int32_t bh, int32_t bw, float global_scale_f,
                                const float sharp_lut[8], float* inv_sigma);
+/* LFCoefficients dequant + LF CfL + adaptiveSmooth (LFCoefficients.java:65-180) of one LF group: out[c] [cells_h][cells_w].
+ * base_corr_x/b and color_factor as in jxl_vardct_params. */
+jxl_status jxl_stage_lf_dequant(jxl_ctx* ctx, const jxl_lfquant_desc* d, float base_corr_x, float base_corr_b,
+                                int32_t color_factor, float* const out[3]);
 /* OpsinInverseMatrix.invertXYB (OpsinInverseMatrix.java:105-142), in place on planes[3]. */
 jxl_status jxl_stage_xyb(jxl_ctx* ctx, float* const planes[3], int64_t n,
                          const float matrix[9], const float opsin_bias[3],

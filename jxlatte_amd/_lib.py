@@ -65,6 +65,7 @@ SIGNATURES = {
     "jxl_vardct_begin_frame": (i32, [vp, C.POINTER(abi.VarDCTParams)]),
     "jxl_vardct_set_weights": (i32, [vp, pf, C.c_size_t, pi]),
     "jxl_vardct_set_lfgroup": (i32, [vp, C.POINTER(abi.LFGroupDesc)]),
+    "jxl_vardct_set_lfgroup_lfquant": (i32, [vp, C.POINTER(abi.LFQuantDesc)]),
     "jxl_vardct_put_group": (i32, [vp, i32, i32, pi3, pi]),
     "jxl_vardct_run": (i32, [vp]),
     "jxl_vardct_finish_frame": (i32, [vp, pv3, i64]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "jxl_stage_gab": (i32, [vp, pf3, pf3, i32, i32, pf, pf]),
     "jxl_stage_epf": (i32, [vp, pf3, pf3, i32, i32, i32, pf, f32, pf, f32, f32, f32]),
     "jxl_stage_epf_sigma": (i32, [vp, pi, pi, i32, i32, f32, pf, pf]),
+    "jxl_stage_lf_dequant": (i32, [vp, C.POINTER(abi.LFQuantDesc), f32, f32, i32, pf3]),
     "jxl_stage_xyb": (i32, [vp, pf3, i64, pf, pf, pf, f32]),
     "jxl_stage_ycbcr": (i32, [vp, pf3, i64]),
     "jxl_stage_transfer": (i32, [vp, pf, i64, i32, i32, pf, pi]),

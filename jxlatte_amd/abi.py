@@ -60,6 +60,11 @@ def tt_matrix_size(param_index):
     raise KeyError(param_index)
 
 
+def iptr(a):
+    assert a.dtype == np.int32
+    return ptr(a, C.c_int32)
+
+
 f3 = C.c_float * 3
 f8 = C.c_float * 8
 f9 = C.c_float * 9
@@ -91,6 +96,30 @@ class LFGroupDesc(C.Structure):
     ]
 
 
+class LFQuantDesc(C.Structure):
+    """struct jxl_lfquant_desc (row f1: integer LF image of one LF group)"""
+    _fields_ = [
+        ("lfg_y", C.c_int32), ("lfg_x", C.c_int32), ("cells_h", C.c_int32), ("cells_w", C.c_int32),
+        ("lf_quant", C.POINTER(C.c_int32) * 3), ("extra_precision", C.c_int32), ("scaled_dequant", f3),
+        ("x_factor_lf", C.c_int32), ("b_factor_lf", C.c_int32), ("adaptive_smoothing", C.c_int32),
+    ]
+
+
+def make_lfquant_desc(lf_quant, scaled_dequant, extra_precision=0, x_factor_lf=128, b_factor_lf=128, adaptive_smoothing=True,
+                      lfg_y=0, lfg_x=0):
+    """lf_quant: int32 array [3][H][W] in X,Y,B order (kept alive by the caller)."""
+    assert lf_quant.dtype == np.int32 and lf_quant.ndim == 3 and lf_quant.flags["C_CONTIGUOUS"]
+    d = LFQuantDesc()
+    d.lfg_y, d.lfg_x = lfg_y, lfg_x
+    d.cells_h, d.cells_w = lf_quant.shape[1:]
+    for c in range(3):
+        d.lf_quant[c] = iptr(lf_quant[c])
+        d.scaled_dequant[c] = scaled_dequant[c]
+    d.extra_precision, d.x_factor_lf, d.b_factor_lf = extra_precision, x_factor_lf, b_factor_lf
+    d.adaptive_smoothing = 1 if adaptive_smoothing else 0
+    return d
+
+
 class SqueezeParam(C.Structure):
     """struct jxl_squeeze_param (SqueezeParam.java)"""
     _fields_ = [("horizontal", C.c_int32), ("in_place", C.c_int32), ("begin_c", C.c_int32), ("num_c", C.c_int32)]
@@ -115,9 +144,6 @@ def fptr(a):
     return ptr(a, C.c_float)
 
 
-def iptr(a):
-    assert a.dtype == np.int32
-    return ptr(a, C.c_int32)
 
 
 def make_lfgroup_desc(g):
@@ -132,8 +158,9 @@ def make_lfgroup_desc(g):
     d.b_from_y = iptr(g["b_from_y"])
     d.block_yx = iptr(g["block_yx"])
     d.n_blocks = g["block_yx"].shape[0]
-    for c in range(3):
-        d.lf[c] = fptr(g["lf"][c])
+    if g.get("lf") is not None:
+        for c in range(3):
+            d.lf[c] = fptr(g["lf"][c])
     return d
 
 

@@ -78,6 +78,9 @@ struct jxl_ctx {
     std::vector<float> h_lf[3];
     std::vector<std::vector<DevBlock>> lfg_blocks;  // per LF group, reference order, frame coordinates
     std::vector<uint8_t> lfg_set;
+    struct LfJob { jxl_lfquant_desc d; std::vector<int32_t> q[3]; };
+    std::vector<LfJob> lf_jobs;  // integer LF images to dequantise + smooth on the device (row f1)
+    DevBuf lfq_tmp[3];
     // binned work
     struct TypeLaunch { int type, items_off, n_items; };
     std::vector<TypeLaunch> type_launches;
@@ -252,11 +255,27 @@ jxl_status finalize_tables(jxl_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->sharp.p, c->h_sharp.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->xfy.p, c->h_xfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->bfy.p, c->h_bfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
-    for (int ch = 0; ch < 3; ch++) {
+    for (int ch = 0; ch < 3; ch++)
         HIP_TRY(c, hipMemcpyAsync(c->lf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
-        // llf starts as a copy of lf (the LLF of an 8x8 block is its LF sample); k_llf overwrites the cells of larger blocks
-        HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    // row f1: LF groups handed over as integers are dequantised + smoothed on the device, over the uploaded planes
+    for (const auto& job : c->lf_jobs) {
+        const jxl_lfquant_desc& d = job.d;
+        const size_t n = (size_t)d.cells_h * d.cells_w;
+        const int32_t* dq[3];
+        for (int ch = 0; ch < 3; ch++) {
+            if (!c->lfq_tmp[ch].ensure(4 * std::max<size_t>(1, n))) return fail(c, JXL_ERR_OOM, "device allocation failed (LF image)");
+            HIP_TRY(c, hipMemcpyAsync(c->lfq_tmp[ch].p, job.q[ch].data(), 4 * n, hipMemcpyHostToDevice, c->stream));
+            dq[ch] = c->lfq_tmp[ch].as<int32_t>();
+        }
+        float* lfp[3] = {c->lf[0].as<float>(), c->lf[1].as<float>(), c->lf[2].as<float>()};
+        launch_lf_dequant(dq, lfp, d.cells_h, d.cells_w, (int64_t)(d.lfg_y * 256) * c->bw + d.lfg_x * 256, c->bw, d.scaled_dequant,
+                          d.extra_precision, c->p.base_corr_x, c->p.base_corr_b, c->p.color_factor, d.x_factor_lf, d.b_factor_lf,
+                          d.adaptive_smoothing, c->stream);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // lfq_tmp is reused by the next job
     }
+    // llf starts as a copy of lf (the LLF of an 8x8 block is its LF sample); k_llf overwrites the cells of larger blocks
+    for (int ch = 0; ch < 3; ch++)
+        HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
     c->tables_dirty = false;
     return JXL_OK;
@@ -381,7 +400,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
                      &c->group_tmp, &c->bad_flag};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 3; i++) {
-        c->coeff[i].release(); c->lf[i].release(); c->llf[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
+        c->coeff[i].release(); c->lf[i].release(); c->llf[i].release(); c->lfq_tmp[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
     }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
@@ -452,6 +471,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     const int nl = ceil_div(c->W, 2048) * ceil_div(c->H, 2048);
     c->lfg_blocks.assign(nl, {});
     c->lfg_set.assign(nl, 0);
+    c->lf_jobs.clear();
     c->tables_dirty = true;
     c->frame_open = true;
     c->ev_runs = 0;
@@ -499,7 +519,7 @@ jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
-    if (!g || !g->dct_select || !g->hf_mul || !g->sharpness || !g->x_from_y || !g->b_from_y || !g->lf[0] || !g->lf[1] || !g->lf[2] ||
+    if (!g || !g->dct_select || !g->hf_mul || !g->sharpness || !g->x_from_y || !g->b_from_y ||
         (g->n_blocks > 0 && !g->block_yx))
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "null pointer in LF group descriptor");
     const int lrs = ceil_div(c->W, 2048), lcs = ceil_div(c->H, 2048);
@@ -515,7 +535,8 @@ jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
             c->h_hf_mul[d] = g->hf_mul[s];
             c->h_sharp[d] = g->sharpness[s];
             c->h_sel[d] = g->dct_select[s];
-            for (int ch = 0; ch < 3; ch++) c->h_lf[ch][d] = g->lf[ch][s];
+            for (int ch = 0; ch < 3; ch++)
+                if (g->lf[ch]) c->h_lf[ch][d] = g->lf[ch][s];
         }
     }
     for (int y = 0; y < gth; y++)
@@ -536,6 +557,62 @@ jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
     }
     c->lfg_set[g->lfg_y * lrs + g->lfg_x] = 1;
     c->tables_dirty = true;
+    return JXL_OK;
+}
+
+static jxl_status check_lfquant(jxl_ctx* c, const jxl_lfquant_desc* d) {
+    if (!d || !d->lf_quant[0] || !d->lf_quant[1] || !d->lf_quant[2]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null LF image");
+    if (d->cells_h <= 0 || d->cells_w <= 0 || d->cells_h > 256 || d->cells_w > 256) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad LF group size");
+    if (d->extra_precision < 0 || d->extra_precision > 3) return fail(c, JXL_ERR_INVALID_BITSTREAM, "extraPrecision %d", d->extra_precision);
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* c, const jxl_lfquant_desc* d) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    if ((st = check_lfquant(c, d))) return st;
+    const int lrs = ceil_div(c->W, 2048), lcs = ceil_div(c->H, 2048);
+    if (d->lfg_x < 0 || d->lfg_x >= lrs || d->lfg_y < 0 || d->lfg_y >= lcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group position out of range");
+    const int eh = std::min(256, c->bh - d->lfg_y * 256), ew = std::min(256, c->bw - d->lfg_x * 256);
+    if (d->cells_h != eh || d->cells_w != ew) return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group (%d,%d) must be %dx%d cells", d->lfg_y, d->lfg_x, eh, ew);
+    jxl_ctx::LfJob job;
+    job.d = *d;
+    const size_t n = (size_t)eh * ew;
+    for (int ch = 0; ch < 3; ch++) {
+        job.q[ch].assign(d->lf_quant[ch], d->lf_quant[ch] + n);
+        job.d.lf_quant[ch] = nullptr;
+    }
+    for (auto& j : c->lf_jobs)
+        if (j.d.lfg_x == d->lfg_x && j.d.lfg_y == d->lfg_y) {
+            j = std::move(job);
+            c->tables_dirty = true;
+            return JXL_OK;
+        }
+    c->lf_jobs.push_back(std::move(job));
+    c->tables_dirty = true;
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_lf_dequant(jxl_ctx* c, const jxl_lfquant_desc* d, float base_corr_x, float base_corr_b, int32_t color_factor,
+                                float* const out[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if ((st = check_lfquant(c, d))) return st;
+    if (!out || !out[0] || !out[1] || !out[2] || color_factor == 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "lf_dequant: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)d->cells_h * d->cells_w;
+    const int32_t* dq[3];
+    float* dout[3];
+    for (int ch = 0; ch < 3; ch++) {
+        dq[ch] = t.up(d->lf_quant[ch], n);
+        dout[ch] = t.up<float>(nullptr, n);
+        if (!dq[ch] || !dout[ch]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    launch_lf_dequant(dq, dout, d->cells_h, d->cells_w, 0, d->cells_w, d->scaled_dequant, d->extra_precision, base_corr_x, base_corr_b,
+                      color_factor, d->x_factor_lf, d->b_factor_lf, d->adaptive_smoothing, c->stream);
+    if ((st = finish(c))) return st;
+    for (int ch = 0; ch < 3; ch++) HIP_TRY(c, hipMemcpy(out[ch], dout[ch], 4 * n, hipMemcpyDeviceToHost));
     return JXL_OK;
 }
 

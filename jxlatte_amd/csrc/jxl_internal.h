@@ -130,6 +130,11 @@ void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh,
 void launch_rct(int32_t* v0, int32_t* v1, int32_t* v2, int64_t n, int type, hipStream_t s);
 void launch_modular_to_float(const int32_t* a, const int32_t* b, int64_t n, float scale, float* out, hipStream_t s);
 
+// LF stage (row f1): q/out device pointers; out written at out_off + y*out_stride + x
+void launch_lf_dequant(const int32_t* const q[3], float* const out[3], int H, int W, int64_t out_off, int out_stride,
+                       const float scaled_dequant[3], int extra_precision, float base_corr_x, float base_corr_b,
+                       int color_factor, int x_factor_lf, int b_factor_lf, int smooth, hipStream_t s);
+
 void launch_idct2d_single(const float* src, float* dst, int h, int w, int transposed, const float* lut, hipStream_t s);
 void launch_fdct2d_single(const float* src, float* dst, int h, int w, const float* lut, hipStream_t s);
 

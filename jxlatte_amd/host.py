@@ -67,6 +67,21 @@ class OpsinInverseMatrix:
         return out
 
 
+class LFCoefficients:
+    """device part of J/frame/vardct/LFCoefficients.java (row f1): dequant, LF chroma-from-luma, adaptiveSmooth"""
+
+    @staticmethod
+    def dequantLFCoeff(ctx, lfQuant, scaledDequant, extraPrecision=0, xFactorLF=128, bFactorLF=128, adaptiveSmoothing=True,
+                       baseCorrelationX=0.0, baseCorrelationB=1.0, colorFactor=84):
+        """lfQuant: int32 [3][H][W] in X,Y,B order (lfQuant[cMap[i]]). Returns float32 [3][H][W]."""
+        q = np.ascontiguousarray(lfQuant, np.int32)
+        d = abi.make_lfquant_desc(q, scaledDequant, extraPrecision, xFactorLF, bFactorLF, adaptiveSmoothing)
+        out = np.empty(q.shape, np.float32)
+        ctx.call("jxl_stage_lf_dequant", C.byref(d), C.c_float(baseCorrelationX), C.c_float(baseCorrelationB), colorFactor,
+                 _p3(out, C.c_float))
+        return out
+
+
 def performColorTransformsYCbCr(ctx, buffer):
     """YCbCr branch of JXLCodestreamDecoder.performColorTransforms (:270-281)"""
     out = np.array(buffer, np.float32, order="C", copy=True)
@@ -144,6 +159,13 @@ class Frame:
     def setLFGroup(self, g):
         d = abi.make_lfgroup_desc(g)
         self.ctx.call("jxl_vardct_set_lfgroup", C.byref(d))
+
+    def setLFGroupQuant(self, lfg_y, lfg_x, lfQuant, scaledDequant, extraPrecision=0, xFactorLF=128, bFactorLF=128,
+                        adaptiveSmoothing=True):
+        """row f1: hand over the integer LF image of an LF group instead of the dequantised floats"""
+        q = np.ascontiguousarray(lfQuant, np.int32)
+        d = abi.make_lfquant_desc(q, scaledDequant, extraPrecision, xFactorLF, bFactorLF, adaptiveSmoothing, lfg_y, lfg_x)
+        self.ctx.call("jxl_vardct_set_lfgroup_lfquant", C.byref(d))
 
     def putGroup(self, pass_, group, q):
         q = [np.ascontiguousarray(a, np.int32) for a in q]

@@ -568,6 +568,67 @@ void orc_epf(const float* const in[3], float* const out[3], int h, int w, int it
     }
 }
 
+/* LFCoefficients ctor tail (LFCoefficients.java:65-103) + adaptiveSmooth (:113-180) */
+void orc_lf_dequant(const jxl_lfquant_desc* d, float base_corr_x, float base_corr_b, int32_t color_factor, float* const out[3]) {
+    const int H = d->cells_h, W = d->cells_w;
+    const size_t n = (size_t)H * W;
+    float* co[3];
+    float* wgt[3];
+    for (int i = 0; i < 3; i++) {
+        co[i] = (float*)malloc(sizeof(float) * (n ? n : 1));
+        wgt[i] = (float*)calloc(n ? n : 1, sizeof(float));
+        const float sd = d->scaled_dequant[i] / (float)(1 << d->extra_precision); /* :69 */
+        for (size_t k = 0; k < n; k++) co[i][k] = (float)d->lf_quant[i][k] * sd;
+    }
+    { /* chroma from luma (:78-95), SPEC: -128 */
+        const float kX = base_corr_x + ((float)d->x_factor_lf - 128.0f) / (float)color_factor;
+        const float kB = base_corr_b + ((float)d->b_factor_lf - 128.0f) / (float)color_factor;
+        for (size_t k = 0; k < n; k++) {
+            co[0][k] += kX * co[1][k];
+            co[2][k] += kB * co[1][k];
+        }
+    }
+    if (!d->adaptive_smoothing) {
+        for (int i = 0; i < 3; i++) memcpy(out[i], co[i], sizeof(float) * n);
+    } else {
+        float* gap = (float*)malloc(sizeof(float) * (n ? n : 1));
+        for (size_t k = 0; k < n; k++) gap[k] = 0.5f; /* rows 1..H-2 are the only ones ever read */
+        for (int i = 0; i < 3; i++) {
+            const float sd = d->scaled_dequant[i];
+            for (int y = 1; y < H - 1; y++) {
+                const float* coy = co[i] + (size_t)y * W;
+                const float* coym = coy - W;
+                const float* coyp = coy + W;
+                for (int x = 1; x < W - 1; x++) {
+                    const float sample = coy[x];
+                    const float adjacent = coy[x - 1] + coy[x + 1] + coym[x] + coyp[x];
+                    const float diag = coym[x - 1] + coym[x + 1] + coyp[x - 1] + coyp[x + 1];
+                    const float wv = 0.05226273532324128f * sample + 0.20345139757231578f * adjacent + 0.0334829185968739f * diag;
+                    wgt[i][(size_t)y * W + x] = wv;
+                    const float g = fabsf(sample - wv) * sd;
+                    if (g > gap[(size_t)y * W + x]) gap[(size_t)y * W + x] = g;
+                }
+            }
+        }
+        for (size_t k = 0; k < n; k++) {
+            const float v = 3.0f - 4.0f * gap[k];
+            gap[k] = v > 0.0f ? v : 0.0f; /* Math.max(0f, 3f - 4f * g) */
+        }
+        for (int i = 0; i < 3; i++)
+            for (int y = 0; y < H; y++)
+                for (int x = 0; x < W; x++) {
+                    const size_t k = (size_t)y * W + x;
+                    if (y == 0 || y + 1 == H || x == 0 || x + 1 == W) out[i][k] = co[i][k];
+                    else out[i][k] = (co[i][k] - wgt[i][k]) * gap[k] + wgt[i][k];
+                }
+        free(gap);
+    }
+    for (int i = 0; i < 3; i++) {
+        free(co[i]);
+        free(wgt[i]);
+    }
+}
+
 /* OpsinInverseMatrix.invertXYB (OpsinInverseMatrix.java:105-142) */
 void orc_xyb(float* const planes[3], int64_t n, const float matrix[9], const float opsin_bias[3],
              const float cbrt_opsin_bias[3], float intensity_target) {

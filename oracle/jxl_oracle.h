@@ -59,6 +59,8 @@ void orc_epf(const float* const in[3], float* const out[3], int h, int w, int it
 void orc_xyb(float* const planes[3], int64_t n, const float matrix[9], const float opsin_bias[3],
              const float cbrt_opsin_bias[3], float intensity_target);
 void orc_ycbcr(float* const planes[3], int64_t n);
+/* LFCoefficients.java:65-180 (dequant, LF chroma-from-luma, adaptiveSmooth) for one LF group */
+void orc_lf_dequant(const jxl_lfquant_desc* d, float base_corr_x, float base_corr_b, int32_t color_factor, float* const out[3]);
 void orc_transfer(const float* in, int64_t n, int transfer, int max_value, float* out_f, int32_t* out_i);
 void orc_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out);
 void orc_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh, int w, int32_t* out);

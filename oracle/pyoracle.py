@@ -174,6 +174,15 @@ def xyb(planes, matrix, opsin_bias, cbrt_opsin_bias, intensity_target):
     return out
 
 
+def lf_dequant(lf_quant, scaled_dequant, extra_precision=0, x_factor_lf=128, b_factor_lf=128, adaptive_smoothing=True,
+               base_corr_x=0.0, base_corr_b=1.0, color_factor=84):
+    q = np.ascontiguousarray(lf_quant, np.int32)
+    d = abi.make_lfquant_desc(q, scaled_dequant, extra_precision, x_factor_lf, b_factor_lf, adaptive_smoothing)
+    out = np.empty(q.shape, np.float32)
+    lib().orc_lf_dequant(C.byref(d), C.c_float(base_corr_x), C.c_float(base_corr_b), C.c_int32(color_factor), _planes3(out, C.c_float))
+    return out
+
+
 def ycbcr(planes):
     out = np.array(planes, np.float32, order="C", copy=True)
     lib().orc_ycbcr(_planes3(out, C.c_float), C.c_int64(out[0].size))
