@@ -188,9 +188,18 @@ def main():
     rest_s = ms_rest * 1e-3
     achieved = rest_bytes / rest_s / 1e9 if rest_s > 0 else 0.0
     path_gbs = path_bytes * fpg * args.steps / elapsed / 1e9
+    # HBM bytes per launch of this kernel from the committed PMC passes of the same configuration (profiles/):
+    # rocprofv3 cannot run inside the bench, so the figure is carried over when the workload matches
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if args.workload == "vardct4k" and args.epf_iters == 2 and os.path.exists(tpath):
+        try:
+            traffic = int(json.load(open(tpath))["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "kernel": "k_restore_fused (Gab, EPF x%d, XYB): HIP events around the launch, frame 0 alone on the device" % args.epf_iters,
         "kernel_ms": round(ms_rest, 4), "algorithmic_bytes_per_launch": int(rest_bytes),
         "kernel_ms_in_batch": round(ms_rest_b, 4),
