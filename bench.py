@@ -159,6 +159,7 @@ def main():
     # ---- optional RCCL gather of the finished pixels to rank 0 (timed on its own)
     gather = None
     if world > 1 and not args.no_gather:
+      try:
         es = lib.jxl_vardct_out_elem_size(ctxs[0].h)
         nbytes = 3 * npx * es * fpg
         send = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -174,6 +175,8 @@ def main():
         dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
         gather = {"ms_per_step": round(float(gdt.item()) * 1e3, 3), "payload_MB_per_rank": round(nbytes / 1e6, 1),
                   "note": "ncclGather of one step's output planes to rank 0; not inside the timed steps"}
+      except Exception as e:  # the optional leg must never take the measurement down
+        gather = {"error": repr(e)[:200]}
 
     if rank != 0:
         if world > 1:
