@@ -41,12 +41,28 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--stages", type=int, default=31, help="stage mask (diagnostics): 1 IDCT, 2 Gab, 4 EPF, 8 XYB, 16 out")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the collective legs even with one rank")
     ap.add_argument("--verify", action="store_true", help="check frame 0 against the oracle before timing")
     return ap.parse_args()
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """the ONE JSON line, on the process's real stdout"""
+    data = (json.dumps(obj) + "\n").encode()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, data)
+
+
 def main():
+    global _REAL_STDOUT
     args = parse()
+    # RCCL prints a version banner on stdout when the first communicator is created; keep stdout clean for the
+    # single JSON line by pointing fd 1 at stderr for the rest of the run
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -55,8 +71,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from jxlatte_amd import _lib, abi, host, synth
 
@@ -104,7 +122,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -118,7 +136,7 @@ def main():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     dt = torch.tensor([t2 - t1], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     torch.cuda.synchronize()
@@ -158,7 +176,7 @@ def main():
 
     # ---- optional RCCL gather of the finished pixels to rank 0 (timed on its own)
     gather = None
-    if world > 1 and not args.no_gather:
+    if use_dist and not args.no_gather:
       try:
         es = lib.jxl_vardct_out_elem_size(ctxs[0].h)
         nbytes = 3 * npx * es * fpg
@@ -179,7 +197,7 @@ def main():
         gather = {"error": repr(e)[:200]}
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -247,8 +265,8 @@ def main():
     }
     if gather:
         line["gather"] = gather
-    print(json.dumps(line), flush=True)
-    if world > 1:
+    emit(line)
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -301,7 +319,7 @@ def bench_modular(args, rank, world, local_rank, torch, dist):
         t = time.perf_counter() - a
         cpu = {"value": round(npx / t / 1e6, 2), "unit": "Mpixels/s", "cores": os.cpu_count(), "kind": "port",
                "sample": "1 image %dx%dx3, C oracle (H steps OpenMP over rows)" % (W, H), "seconds": round(t, 3)}
-    print(json.dumps({
+    emit({
         "metric": "Mpixels/s inverse Squeeze (Modular %dx%d, 3 channels, default squeeze plan)" % (W, H),
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -312,7 +330,7 @@ def bench_modular(args, rank, world, local_rank, torch, dist):
                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                      "note": "whole step list; the squeeze recurrence is serial along the axis (latency-bound)"},
         "cpu_baseline": cpu,
-    }), flush=True)
+    })
 
 
 if __name__ == "__main__":
