@@ -51,6 +51,10 @@ typedef int32_t jxl_status;
 #define JXL_OUT_F32 0       /* float planes */
 #define JXL_OUT_U16 1       /* ImageBuffer.castToIntWithMax(65535), ImageBuffer.java:129-147 */
 #define JXL_OUT_U8  2       /* ImageBuffer.castToIntWithMax(255) */
+/* row f3: the same quantised samples, pixel-interleaved R,G,B in the order PNGWriter.writeIDAT emits them
+ * (PNGWriter.java:191-203); one buffer of height*width*3 elements (out[0]; out[1], out[2] unused). u16 is host order. */
+#define JXL_OUT_RGB8  3
+#define JXL_OUT_RGB16 4
 
 /* stage mask bits for jxl_vardct_params.stages */
 #define JXL_STAGE_IDCT 1u  /* dequant + CfL + LLF + inverse transforms (PassGroup.invertVarDCT) */
@@ -242,6 +246,70 @@ jxl_status jxl_stage_rct(jxl_ctx* ctx, int32_t* const v[3], int64_t n, int32_t r
  * out = scale * (a + b) (b may be NULL) as float. */
 jxl_status jxl_stage_modular_to_float(jxl_ctx* ctx, const int32_t* a, const int32_t* b, int64_t n,
                                       float scale, float* out);
+
+/* ---- row f4: pixel-domain stencils that run between EPF and the colour transform ---- */
+/* Frame.invertSubsampling (Frame.java:681-723) for one channel: x_shift horizontal doublings then y_shift
+ * vertical doublings (3/4, 1/4 triangle, replicated edges). out is (h << y_shift) x (w << x_shift). */
+jxl_status jxl_stage_chroma_upsample(jxl_ctx* ctx, const float* in, int32_t h, int32_t w, int32_t x_shift,
+                                     int32_t y_shift, float* out);
+/* ImageHeader.getUpWeights index expansion (ImageHeader.java:441-470): packed = the k==2: 15, k==4: 55,
+ * k==8: 210 coefficient list of the image header; out = [k][k][5][5]. Host-only helper, no device work. */
+jxl_status jxl_upsampling_weights(int32_t k, const float* packed, float* out);
+/* Frame.performUpsampling (Frame.java:217-260): k in {2,4,8}, weights [k][k][5][5], mirrored edges,
+ * result clamped to the reference's [min, max] window (max starts at Float.MIN_VALUE, :237). out is (h*k) x (w*k). */
+jxl_status jxl_stage_upsample(jxl_ctx* ctx, const float* in, int32_t h, int32_t w, int32_t k, const float* weights,
+                              float* out);
+/* Frame.initializeNoise (Frame.java:748-788): per-group XorShiro streams (features/XorShiro.java) turned into
+ * floats in [1,2), then the 5x5 "laplacian" high-pass with mirrored edges. seed0 = (visibleFrames << 32) |
+ * invisibleFrames (JXLCodestreamDecoder.java:629). out[c]: h x w, c < colors. */
+jxl_status jxl_stage_noise_init(jxl_ctx* ctx, int32_t h, int32_t w, int32_t group_dim, uint64_t seed0, int32_t colors,
+                                float* const out[3]);
+/* Frame.synthesizeNoise (Frame.java:790-831), in place on the XYB planes[3] (X, Y, B); lut = LFGlobal.noiseParameters[8]. */
+jxl_status jxl_stage_noise_add(jxl_ctx* ctx, float* const planes[3], const float* const noise[3], int64_t n,
+                               const float lut[8], float base_corr_x, float base_corr_b);
+
+/* ---- row f3: output stage (blending, orientation, sample packing) ---- */
+#define JXL_BLEND_REPLACE 0 /* FrameFlags.java:18-22 */
+#define JXL_BLEND_ADD     1
+#define JXL_BLEND_BLEND   2
+#define JXL_BLEND_MULADD  3
+#define JXL_BLEND_MULT    4
+#define JXL_BLEND_FLAG_IS_ALPHA  1u /* this channel is the alpha channel itself */
+#define JXL_BLEND_FLAG_HAS_EXTRA 2u /* the image has extra channels (else BLEND / MULADD degrade to ADD) */
+#define JXL_BLEND_FLAG_CLAMP     4u /* BlendingInfo.clamp */
+#define JXL_BLEND_FLAG_PREMULT   8u /* alpha is associated */
+typedef struct jxl_blend_rect {
+    int32_t h, w;               /* blendSize */
+    int32_t canvas_y, canvas_x; /* patchStart: where the rectangle lands on the canvas */
+    int32_t frame_y, frame_x;   /* frameOffset: its origin inside the frame buffers */
+    int32_t ref_y, ref_x;       /* refOffset: its origin inside the reference buffers */
+} jxl_blend_rect;
+/* One channel of JXLCodestreamDecoder.blendBuffers' inner switch (JXLCodestreamDecoder.java:26-40 copyToCanvas,
+ * :285-318 blendAdd, :320-340 blendMult, :342-386 blendBlend, :388-422 blendMulAdd). "frame" and "ref" are the
+ * arguments those functions receive under these names. canvas is ch x cw and updated in place inside the rectangle;
+ * frame / frame_alpha are fh x fw; ref / ref_alpha are rh x rw. is_int: samples are int32 (REPLACE and the ADD
+ * cases only), else float. Unused planes may be NULL. */
+jxl_status jxl_stage_blend(jxl_ctx* ctx, int32_t mode, uint32_t flags, int32_t is_int,
+                           void* canvas, int32_t ch, int32_t cw, const void* frame, int32_t fh, int32_t fw,
+                           const void* ref, int32_t rh, int32_t rw, const float* frame_alpha, const float* ref_alpha,
+                           const jxl_blend_rect* rect);
+/* JXLCodestreamDecoder.transposeBufferFloat / transposeBufferInt (:43-177): EXIF orientation 1..8 of one plane of
+ * 4-byte samples. out is h x w for orientation <= 4, else w x h. */
+jxl_status jxl_stage_orient(jxl_ctx* ctx, const void* in, int32_t h, int32_t w, int32_t orientation, void* out);
+/* PNGWriter ctor tail + writeIDAT sample order (PNGWriter.java:79-111, 191-203): coerce to float when needed,
+ * un-premultiply, quantise / clamp to bit_depth, and interleave colour channels then alpha. */
+typedef struct jxl_pack_params {
+    int32_t height, width;
+    int32_t n_color;         /* 1 (gray) or 3 */
+    int32_t has_alpha;       /* planes[n_color] is the alpha plane */
+    int32_t premultiplied;   /* image.isAlphaPremultiplied() */
+    int32_t bit_depth;       /* 8 or 16 */
+    int32_t big_endian;      /* 16-bit samples as DataOutput.writeShort emits them (PNG), else host order */
+    int32_t is_int[4];       /* plane holds int32 samples (else float) */
+    int32_t tagged_depth[4]; /* image.getTaggedBitDepth(c) */
+} jxl_pack_params;
+/* out: height * width * (n_color + has_alpha) samples of 1 or 2 bytes */
+jxl_status jxl_stage_pack(jxl_ctx* ctx, const void* const planes[4], const jxl_pack_params* p, void* out);
 
 /* ---- Modular path: replaces ModularStream.applyTransforms squeeze/RCT branches ---- */
 /* Default squeeze parameter list of ModularStream.java:110-131 for a channel list whose

@@ -88,6 +88,15 @@ SIGNATURES = {
     "jxl_stage_inv_vsqueeze": (i32, [vp, pi, i32, pi, i32, i32, pi]),
     "jxl_stage_rct": (i32, [vp, pi3, i64, i32]),
     "jxl_stage_modular_to_float": (i32, [vp, pi, pi, i64, f32, pf]),
+    "jxl_stage_chroma_upsample": (i32, [vp, pf, i32, i32, i32, i32, pf]),
+    "jxl_upsampling_weights": (i32, [i32, pf, pf]),
+    "jxl_stage_upsample": (i32, [vp, pf, i32, i32, i32, pf, pf]),
+    "jxl_stage_noise_init": (i32, [vp, i32, i32, i32, C.c_uint64, i32, pf3]),
+    "jxl_stage_noise_add": (i32, [vp, pf3, pf3, i64, pf, f32, f32]),
+    "jxl_stage_blend": (i32, [vp, i32, C.c_uint32, i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, pf, pf,
+                              C.POINTER(abi.BlendRect)]),
+    "jxl_stage_orient": (i32, [vp, vp, i32, i32, i32, vp]),
+    "jxl_stage_pack": (i32, [vp, pv3, C.POINTER(abi.PackParams), vp]),
     "jxl_modular_default_squeeze_params": (i32, [pi, pi, i32, i32, C.POINTER(abi.SqueezeParam), i32]),
     "jxl_modular_squeezed_shapes": (i32, [pi, pi, i32, C.POINTER(abi.SqueezeParam), i32, pi, pi, i32]),
     "jxl_modular_begin": (i32, [vp, C.POINTER(abi.Channel), i32, C.POINTER(abi.SqueezeParam), i32, i32, i32]),

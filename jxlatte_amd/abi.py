@@ -16,7 +16,9 @@ JXL_ERR_OOM = -5
 JXL_ERR_STATE = -6
 
 TRANSFER_NONE, TRANSFER_PQ, TRANSFER_SRGB = 0, 1, 2
-OUT_F32, OUT_U16, OUT_U8 = 0, 1, 2
+OUT_F32, OUT_U16, OUT_U8, OUT_RGB8, OUT_RGB16 = 0, 1, 2, 3, 4
+BLEND_REPLACE, BLEND_ADD, BLEND_BLEND, BLEND_MULADD, BLEND_MULT = 0, 1, 2, 3, 4
+BLEND_FLAG_IS_ALPHA, BLEND_FLAG_HAS_EXTRA, BLEND_FLAG_CLAMP, BLEND_FLAG_PREMULT = 1, 2, 4, 8
 STAGE_IDCT, STAGE_GAB, STAGE_EPF, STAGE_XYB, STAGE_OUT = 1, 2, 4, 8, 16
 STAGE_ALL = 31
 
@@ -118,6 +120,19 @@ def make_lfquant_desc(lf_quant, scaled_dequant, extra_precision=0, x_factor_lf=1
     d.extra_precision, d.x_factor_lf, d.b_factor_lf = extra_precision, x_factor_lf, b_factor_lf
     d.adaptive_smoothing = 1 if adaptive_smoothing else 0
     return d
+
+
+class BlendRect(C.Structure):
+    """struct jxl_blend_rect"""
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("canvas_y", C.c_int32), ("canvas_x", C.c_int32),
+                ("frame_y", C.c_int32), ("frame_x", C.c_int32), ("ref_y", C.c_int32), ("ref_x", C.c_int32)]
+
+
+class PackParams(C.Structure):
+    """struct jxl_pack_params"""
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("n_color", C.c_int32), ("has_alpha", C.c_int32),
+                ("premultiplied", C.c_int32), ("bit_depth", C.c_int32), ("big_endian", C.c_int32),
+                ("is_int", C.c_int32 * 4), ("tagged_depth", C.c_int32 * 4)]
 
 
 class SqueezeParam(C.Structure):

@@ -91,6 +91,7 @@ struct jxl_ctx {
     // results
     void* result[3] = {nullptr, nullptr, nullptr};
     int result_elem = 4;
+    bool result_interleaved = false;
     int last_launches = 0;
     bool timing = false;
     static constexpr int kEvSlots = 32;
@@ -326,7 +327,9 @@ XybParams make_xyb(const float m[9], const float ob[3], const float cob[3], floa
     return x;
 }
 
-int out_elem_size(int fmt) { return fmt == JXL_OUT_U16 ? 2 : fmt == JXL_OUT_U8 ? 1 : 4; }
+int out_elem_size(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 2 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 1 : 4; }
+int out_max_value(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 65535 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 255 : 0; }
+bool out_interleaved(int fmt) { return fmt == JXL_OUT_RGB8 || fmt == JXL_OUT_RGB16; }
 
 }  // namespace
 
@@ -442,7 +445,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     if (p->width <= 0 || p->height <= 0 || (p->width & 7) || (p->height & 7))
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "padded frame size %dx%d must be positive multiples of 8", p->width, p->height);
     if (p->epf_iters < 0 || p->epf_iters > 3) return fail(c, JXL_ERR_INVALID_BITSTREAM, "epfIterations %d", p->epf_iters);
-    if (p->out_format < 0 || p->out_format > 2 || p->transfer < 0 || p->transfer > 2)
+    if (p->out_format < 0 || p->out_format > JXL_OUT_RGB16 || p->transfer < 0 || p->transfer > 2)
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output stage selector");
     c->p = *p;
     c->W = p->width; c->H = p->height;
@@ -453,7 +456,8 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     for (int i = 0; i < 3; i++) {
         ok = ok && c->coeff[i].ensure(4 * npx) && c->planeA[i].ensure(4 * npx) && c->planeB[i].ensure(4 * npx) &&
              c->lf[i].ensure(4 * nc) && c->llf[i].ensure(4 * nc);
-        if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
+        if (out_interleaved(p->out_format)) ok = ok && (i > 0 || c->outbuf[0].ensure(3 * (size_t)out_elem_size(p->out_format) * npx));
+        else if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
     }
     ok = ok && c->hf_mul.ensure(4 * nc) && c->sharp.ensure(4 * nc) && c->xfy.ensure(4 * nt) && c->bfy.ensure(4 * nt) &&
          c->inv_sigma.ensure(4 * nc) && c->group_tmp.ensure(4 * 256 * 256);
@@ -712,8 +716,9 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         RestoreParams rp{};
         rp.gab = do_gab; rp.epf_iters = do_epf ? p.epf_iters : 0; rp.xyb = do_xyb;
         rp.transfer = do_out ? p.transfer : JXL_TRANSFER_NONE;
-        rp.max_value = do_out ? (p.out_format == JXL_OUT_U16 ? 65535 : p.out_format == JXL_OUT_U8 ? 255 : 0) : 0;
+        rp.max_value = do_out ? out_max_value(p.out_format) : 0;
         rp.out_elem = do_out ? out_elem_size(p.out_format) : 4;
+        rp.interleaved = do_out && out_interleaved(p.out_format);
         for (int i = 0; i < 3; i++) {
             const float mult = 1.0f / (1.0f + 4.0f * (p.gab_w1[i] + p.gab_w2[i]));  // Frame.java:510-517
             rp.gab_base[i] = mult; rp.gab_adj[i] = p.gab_w1[i] * mult; rp.gab_diag[i] = p.gab_w2[i] * mult;
@@ -730,6 +735,7 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
             launches++;
             for (int i = 0; i < 3; i++) c->result[i] = dst[i];
             c->result_elem = rp.out_elem;
+            c->result_interleaved = rp.interleaved != 0;
         }
     }
     if (!fused) {
@@ -758,17 +764,20 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
             launches++;
         }
         if (do_out) {
-            const int maxv = p.out_format == JXL_OUT_U16 ? 65535 : p.out_format == JXL_OUT_U8 ? 255 : 0;
+            const int maxv = out_max_value(p.out_format);
             const int es = out_elem_size(p.out_format);
+            const bool il = out_interleaved(p.out_format);
             for (int i = 0; i < 3; i++) {
-                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer, maxv, c->outbuf[i].p, es, s);
+                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer, maxv, c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0);
                 c->result[i] = c->outbuf[i].p;
                 launches++;
             }
             c->result_elem = es;
+            c->result_interleaved = il;
         } else {
             for (int i = 0; i < 3; i++) c->result[i] = cur[i];
             c->result_elem = 4;
+            c->result_interleaved = false;
         }
     }
     if (c->timing) {
@@ -808,6 +817,12 @@ jxl_status jxl_vardct_read_output(jxl_ctx* c, void* const out[3], int64_t out_st
     if (!out || out_stride < c->W) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output planes");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t es = (size_t)c->result_elem;
+    if (c->result_interleaved) {  // one buffer, rows of 3*W samples; out_stride counts pixels
+        if (!out[0]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output buffer");
+        HIP_TRY(c, hipMemcpy2D(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
+                               hipMemcpyDeviceToHost));
+        return JXL_OK;
+    }
     for (int i = 0; i < 3; i++) {
         if (!out[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane %d", i);
         HIP_TRY(c, hipMemcpy2D(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H, hipMemcpyDeviceToHost));
@@ -828,6 +843,10 @@ jxl_status jxl_vardct_copy_output_device(jxl_ctx* c, void* dst_device) {
     if (st) return st;
     if (!c->result[0] || !dst_device) return fail(c, JXL_ERR_STATE, "nothing has been run");
     const size_t bytes = (size_t)c->W * c->H * c->result_elem;
+    if (c->result_interleaved) {
+        HIP_TRY(c, hipMemcpyAsync(dst_device, c->result[0], 3 * bytes, hipMemcpyDeviceToDevice, c->stream));
+        return JXL_OK;
+    }
     for (int i = 0; i < 3; i++)
         HIP_TRY(c, hipMemcpyAsync((char*)dst_device + i * bytes, c->result[i], bytes, hipMemcpyDeviceToDevice, c->stream));
     return JXL_OK;
@@ -1053,6 +1072,188 @@ jxl_status jxl_stage_modular_to_float(jxl_ctx* c, const int32_t* a, const int32_
     launch_modular_to_float(da, db, n, scale, dd, c->stream);
     if ((st = finish(c))) return st;
     HIP_TRY(c, hipMemcpy(out, dd, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+
+// ---- rows f4 / f3: stage-level entries ----------------------------------------------------------------
+jxl_status jxl_stage_chroma_upsample(jxl_ctx* c, const float* in, int32_t h, int32_t w, int32_t x_shift, int32_t y_shift,
+                                     float* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!in || !out || h <= 0 || w <= 0 || x_shift < 0 || y_shift < 0 || x_shift > 2 || y_shift > 2)
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "chroma_upsample: bad arguments");
+    Tmp t;
+    const size_t cap = ((size_t)h << y_shift) * ((size_t)w << x_shift);
+    float* cur = t.up<float>(nullptr, cap);
+    float* nxt = t.up<float>(nullptr, cap);
+    if (!cur || !nxt) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    HIP_TRY(c, hipMemcpy(cur, in, sizeof(float) * (size_t)h * w, hipMemcpyHostToDevice));
+    int ch = h, cw = w;
+    for (int i = 0; i < x_shift; i++) {  // Frame.java:684-699
+        launch_chroma_upsample_h(cur, ch, cw, nxt, c->stream);
+        cw *= 2;
+        std::swap(cur, nxt);
+    }
+    for (int i = 0; i < y_shift; i++) {  // :701-720
+        launch_chroma_upsample_v(cur, ch, cw, nxt, c->stream);
+        ch *= 2;
+        std::swap(cur, nxt);
+    }
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, cur, sizeof(float) * cap, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_upsampling_weights(int32_t k, const float* packed, float* out) {
+    if ((k != 2 && k != 4 && k != 8) || !packed || !out) return JXL_ERR_INVALID_ARGUMENT;
+    // ImageHeader.java:454-466: the k*k 5x5 kernels are mirror images of a symmetric (5k/2)x(5k/2) table stored as its
+    // upper triangle
+    for (int ky = 0; ky < k; ky++)
+        for (int kx = 0; kx < k; kx++)
+            for (int iy = 0; iy < 5; iy++)
+                for (int ix = 0; ix < 5; ix++) {
+                    const int j = ky < k / 2 ? iy + 5 * ky : (4 - iy) + 5 * (k - 1 - ky);
+                    const int i = kx < k / 2 ? ix + 5 * kx : (4 - ix) + 5 * (k - 1 - kx);
+                    const int hi = std::max(i, j), lo = std::min(i, j);
+                    out[((ky * k + kx) * 5 + iy) * 5 + ix] = packed[5 * k * lo / 2 - lo * (lo - 1) / 2 + hi - lo];
+                }
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_upsample(jxl_ctx* c, const float* in, int32_t h, int32_t w, int32_t k, const float* weights, float* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!in || !out || !weights || h <= 0 || w <= 0 || (k != 2 && k != 4 && k != 8))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "upsample: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)h * w;
+    float* di = t.up(in, n);
+    float* dw = t.up(weights, (size_t)k * k * 25);
+    float* dout = t.up<float>(nullptr, n * k * k);
+    if (!di || !dw || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_upsample(di, h, w, k, dw, dout, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, dout, sizeof(float) * n * k * k, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_noise_init(jxl_ctx* c, int32_t h, int32_t w, int32_t group_dim, uint64_t seed0, int32_t colors,
+                                float* const out[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!out || h <= 0 || w <= 0 || group_dim < 16 || (group_dim & (group_dim - 1)) || colors < 1 || colors > 3)
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "noise_init: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)h * w;
+    float* tmp[3] = {nullptr, nullptr, nullptr};
+    float* dout[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < colors; i++) {
+        tmp[i] = t.up<float>(nullptr, n);
+        dout[i] = t.up<float>(nullptr, n);
+        if (!tmp[i] || !dout[i] || !out[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    launch_noise_init(h, w, group_dim, seed0, colors, tmp, dout, c->stream);
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < colors; i++) HIP_TRY(c, hipMemcpy(out[i], dout[i], 4 * n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_noise_add(jxl_ctx* c, float* const planes[3], const float* const noise[3], int64_t n, const float lut[8],
+                               float base_corr_x, float base_corr_b) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!planes || !noise || !lut || n < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "noise_add: bad arguments");
+    Tmp t;
+    float* d[3];
+    const float* dn[3];
+    for (int i = 0; i < 3; i++) {
+        d[i] = t.up(planes[i], (size_t)n);
+        dn[i] = t.up(noise[i], (size_t)n);
+        if (!d[i] || !dn[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    if (n > 0) launch_noise_add(d, dn, n, lut, base_corr_x, base_corr_b, c->stream);
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpy(planes[i], d[i], 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_blend(jxl_ctx* c, int32_t mode, uint32_t flags, int32_t is_int, void* canvas, int32_t ch, int32_t cw,
+                           const void* frame, int32_t fh, int32_t fw, const void* ref, int32_t rh, int32_t rw,
+                           const float* frame_alpha, const float* ref_alpha, const jxl_blend_rect* r) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!canvas || !r || ch <= 0 || cw <= 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "blend: bad arguments");
+    const int op = blend_op(mode, flags, is_int);
+    if (op == -1) return fail(c, JXL_ERR_INVALID_BITSTREAM, "Illegal blend mode");  // JXLCodestreamDecoder.java:506
+    if (op == -2) return fail(c, JXL_ERR_INVALID_ARGUMENT, "blend: this mode works on float samples");
+    bool nf, nr, nfa, nra;
+    blend_needs(op, &nf, &nr, &nfa, &nra, (flags & JXL_BLEND_FLAG_IS_ALPHA) != 0);
+    if ((nf && !frame) || (nr && !ref) || (nfa && !frame_alpha) || (nra && !ref_alpha))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "blend: a plane this mode reads is NULL");
+    // the rectangle must lie inside every plane that is touched (Java would throw ArrayIndexOutOfBounds)
+    auto inside = [&](int y, int x, int H, int W) { return r->h >= 0 && r->w >= 0 && y >= 0 && x >= 0 && y + r->h <= H && x + r->w <= W; };
+    const bool copy_ref = nr && !nf;  // blendMulAdd's alpha case indexes ref with frameOffset
+    if (!inside(r->canvas_y, r->canvas_x, ch, cw) || ((nf || nfa) && !inside(r->frame_y, r->frame_x, fh, fw)) ||
+        ((nr || nra) && !inside(copy_ref ? r->frame_y : r->ref_y, copy_ref ? r->frame_x : r->ref_x, rh, rw)))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "blend: rectangle outside a plane");
+    Tmp t;
+    uint32_t* dc = t.up((const uint32_t*)canvas, (size_t)ch * cw);
+    uint32_t* df = nf ? t.up((const uint32_t*)frame, (size_t)fh * fw) : nullptr;
+    uint32_t* dr = nr ? t.up((const uint32_t*)ref, (size_t)rh * rw) : nullptr;
+    float* dfa = nfa ? t.up(frame_alpha, (size_t)fh * fw) : nullptr;
+    float* dra = nra ? t.up(ref_alpha, (size_t)rh * rw) : nullptr;
+    if (!dc || (nf && !df) || (nr && !dr) || (nfa && !dfa) || (nra && !dra)) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_blend(op, flags, dc, cw, df, fw, dr, rw, dfa, dra, *r, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(canvas, dc, 4 * (size_t)ch * cw, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_orient(jxl_ctx* c, const void* in, int32_t h, int32_t w, int32_t orientation, void* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (orientation < 1 || orientation > 8) return fail(c, JXL_ERR_STATE, "orientation %d", orientation);  // IllegalStateException, :107
+    if (!in || !out || h <= 0 || w <= 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "orient: bad arguments");
+    Tmp t;
+    const size_t n = (size_t)h * w;
+    uint32_t* di = t.up((const uint32_t*)in, n);
+    uint32_t* dout = t.up<uint32_t>(nullptr, n);
+    if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_orient(di, h, w, orientation, dout, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, dout, 4 * n, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_stage_pack(jxl_ctx* c, const void* const planes[4], const jxl_pack_params* p, void* out) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!planes || !p || !out || p->height <= 0 || p->width <= 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "pack: bad arguments");
+    if (p->bit_depth != 8 && p->bit_depth != 16) return fail(c, JXL_ERR_INVALID_ARGUMENT, "PNG only supports 8 and 16");  // PNGWriter.java:57-58
+    if ((p->n_color != 1 && p->n_color != 3) || (p->premultiplied && !p->has_alpha))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "pack: bad channel layout");
+    const int nch = p->n_color + (p->has_alpha ? 1 : 0);
+    bool coerce = p->premultiplied != 0;  // PNGWriter.java:79-88
+    for (int i = 0; i < nch && !coerce; i++) coerce = p->is_int[i] && p->tagged_depth[i] != p->bit_depth;
+    for (int i = 0; i < nch; i++) {
+        if (!planes[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "pack: null plane %d", i);
+        if (coerce && p->is_int[i] && (p->tagged_depth[i] < 1 || p->tagged_depth[i] > 31))
+            return fail(c, JXL_ERR_INVALID_ARGUMENT, "invalid Max Value");  // ImageBuffer.java:115-116
+    }
+    Tmp t;
+    const size_t n = (size_t)p->height * p->width;
+    const void* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < nch; i++) {
+        d[i] = t.up((const uint32_t*)planes[i], n);
+        if (!d[i]) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    }
+    const size_t ob = n * nch * (p->bit_depth / 8);
+    uint8_t* dout = t.up<uint8_t>(nullptr, ob);
+    if (!dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    launch_pack(d, *p, coerce, dout, c->stream);
+    if ((st = finish(c))) return st;
+    HIP_TRY(c, hipMemcpy(out, dout, ob, hipMemcpyDeviceToHost));
     return JXL_OK;
 }
 

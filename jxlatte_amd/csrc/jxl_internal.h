@@ -97,10 +97,13 @@ void launch_epf_iter(const float* const in[3], float* const out[3], int h, int w
 void launch_xyb(float* const planes[3], int64_t n, const XybParams& p, hipStream_t s);
 void launch_ycbcr(float* const planes[3], int64_t n, hipStream_t s);
 // transfer + quantise: out elem size 4 (float or int32), 2 (u16), 1 (u8)
-void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s);
+// out index = i * out_pitch + out_off (pitch 1 = planar; pitch 3, off c = pixel-interleaved)
+void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s,
+                     int out_pitch = 1, int out_off = 0);
 // fused restoration + colour tile kernel (Gab -> EPF iters -> XYB -> optional transfer/quantise)
 struct RestoreParams {
     int gab, epf_iters, xyb, transfer, max_value, out_elem;
+    int interleaved;  // JXL_OUT_RGB8 / RGB16: out[0] holds R,G,B per pixel
     float gab_base[3], gab_adj[3], gab_diag[3];
     EpfParams epf[3];  // per iteration index 0..2
     XybParams xybp;
@@ -134,6 +137,22 @@ void launch_modular_to_float(const int32_t* a, const int32_t* b, int64_t n, floa
 void launch_lf_dequant(const int32_t* const q[3], float* const out[3], int H, int W, int64_t out_off, int out_stride,
                        const float scaled_dequant[3], int extra_precision, float base_corr_x, float base_corr_b,
                        int color_factor, int x_factor_lf, int b_factor_lf, int smooth, hipStream_t s);
+
+// rows f4 / f3 (k_post.hip); all pointers are device pointers
+void launch_chroma_upsample_h(const float* in, int h, int w, float* out, hipStream_t s);
+void launch_chroma_upsample_v(const float* in, int h, int w, float* out, hipStream_t s);
+void launch_upsample(const float* in, int h, int w, int k, const float* weights, float* out, hipStream_t s);
+void launch_noise_init(int h, int w, int group_dim, uint64_t seed0, int colors, float* const tmp[3], float* const out[3],
+                       hipStream_t s);
+void launch_noise_add(float* const planes[3], const float* const noise[3], int64_t n, const float lut[8], float bcx, float bcb,
+                      hipStream_t s);
+// maps (mode, flags, is_int) to the inner blend function; -1 illegal mode, -2 int samples on a float-only function
+int blend_op(int mode, unsigned flags, int is_int);
+bool blend_needs(int op, bool* frame, bool* ref, bool* frame_alpha, bool* ref_alpha, bool is_alpha);
+void launch_blend(int op, unsigned flags, void* canvas, int cw, const void* frame, int fw, const void* ref, int rw,
+                  const float* frame_alpha, const float* ref_alpha, const jxl_blend_rect& r, hipStream_t s);
+void launch_orient(const void* in, int h, int w, int orientation, void* out, hipStream_t s);
+void launch_pack(const void* const planes[4], const jxl_pack_params& p, bool coerce, void* out, hipStream_t s);
 
 void launch_idct2d_single(const float* src, float* dst, int h, int w, int transposed, const float* lut, hipStream_t s);
 void launch_fdct2d_single(const float* src, float* dst, int h, int w, const float* lut, hipStream_t s);

@@ -290,7 +290,10 @@ struct OutSink {
             if (a.p.max_value > 0) {
                 int32_t q = f2i_java(t * (float)a.p.max_value + 0.5f);
                 q = q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
-                if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+                if (a.p.interleaved) {  // R,G,B per pixel in out[0] (PNGWriter.writeIDAT order)
+                    if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
+                    else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
+                } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
                 else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
                 else ((int32_t*)a.out[c])[g] = q;
             } else {

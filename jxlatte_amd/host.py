@@ -182,11 +182,17 @@ class Frame:
         p = self.params
         as_int = (p.stages & abi.STAGE_OUT) and p.out_format != abi.OUT_F32
         dt = {4: np.int32 if as_int else np.float32, 2: np.uint16, 1: np.uint8}[es]
+        if as_int and p.out_format in (abi.OUT_RGB8, abi.OUT_RGB16):  # row f3: one pixel-interleaved buffer
+            return np.empty((self.height, self.width, 3), dt)
         return np.empty((3, self.height, self.width), dt)
 
     def readOutput(self):
         out = self._out_array()
-        pp = (C.c_void_p * 3)(*[out[c].ctypes.data for c in range(3)])
+        if out.shape[-1] == 3 and out.ndim == 3 and out.shape[0] == self.height and out.dtype != np.float32 and \
+                self.params.out_format in (abi.OUT_RGB8, abi.OUT_RGB16):
+            pp = (C.c_void_p * 3)(out.ctypes.data, None, None)
+        else:
+            pp = (C.c_void_p * 3)(*[out[c].ctypes.data for c in range(3)])
         self.ctx.call("jxl_vardct_read_output", pp, self.width)
         return out
 
@@ -325,4 +331,113 @@ def modularToFloat(ctx, a, b, scale):
         b = np.ascontiguousarray(b, np.int32)
         bp = abi.iptr(b)
     ctx.call("jxl_stage_modular_to_float", abi.iptr(a), bp, a.size, C.c_float(scale), abi.fptr(out))
+    return out
+
+
+# ---- rows f4 / f3: the pixel-domain functions either side of the colour transform -------------------------
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def invertSubsampling(ctx, channel, xShift, yShift):
+    """Frame.invertSubsampling (Frame.java:681-723) for one channel"""
+    a = np.ascontiguousarray(channel, np.float32)
+    h, w = a.shape
+    out = np.empty((h << yShift, w << xShift), np.float32)
+    ctx.call("jxl_stage_chroma_upsample", abi.fptr(a), h, w, xShift, yShift, abi.fptr(out))
+    return out
+
+
+def getUpWeights(k, packed):
+    """ImageHeader.getUpWeights (ImageHeader.java:441-470) for one k: [k][k][5][5]"""
+    from ._lib import load
+    packed = np.ascontiguousarray(packed, np.float32)
+    need = {2: 15, 4: 55, 8: 210}.get(k)
+    if need is None or packed.size != need:
+        raise ValueError("k must be 2, 4 or 8 with 15 / 55 / 210 coefficients")
+    out = np.empty((k, k, 5, 5), np.float32)
+    st = load().jxl_upsampling_weights(k, abi.fptr(packed), abi.fptr(out))
+    if st:
+        raise ValueError("status %d" % st)
+    return out
+
+
+def performUpsampling(ctx, channel, k, upWeights):
+    """Frame.performUpsampling (Frame.java:217-260)"""
+    if k == 1:
+        return channel
+    a = np.ascontiguousarray(channel, np.float32)
+    wts = np.ascontiguousarray(upWeights, np.float32)
+    h, w = a.shape
+    out = np.empty((h * k, w * k), np.float32)
+    ctx.call("jxl_stage_upsample", abi.fptr(a), h, w, k, abi.fptr(wts), abi.fptr(out))
+    return out
+
+
+def initializeNoise(ctx, height, width, seed0, groupDim=256, colors=3):
+    """Frame.initializeNoise (Frame.java:748-788)"""
+    out = np.empty((colors, height, width), np.float32)
+    pp = (C.POINTER(C.c_float) * 3)(*[abi.fptr(out[c]) for c in range(colors)])
+    ctx.call("jxl_stage_noise_init", height, width, groupDim, C.c_uint64(seed0 & 0xFFFFFFFFFFFFFFFF), colors, pp)
+    return out
+
+
+def synthesizeNoise(ctx, planes, noise, lut, baseCorrelationX, baseCorrelationB):
+    """Frame.synthesizeNoise (Frame.java:790-831); returns new planes"""
+    out = np.array(planes, np.float32, order="C", copy=True)
+    nz = np.ascontiguousarray(noise, np.float32)
+    lut = np.ascontiguousarray(lut, np.float32)
+    pp = (C.POINTER(C.c_float) * 3)(*[abi.fptr(out[c]) for c in range(3)])
+    pn = (C.POINTER(C.c_float) * 3)(*[abi.fptr(nz[c]) for c in range(3)])
+    ctx.call("jxl_stage_noise_add", pp, pn, out[0].size, abi.fptr(lut), C.c_float(baseCorrelationX), C.c_float(baseCorrelationB))
+    return out
+
+
+def blend(ctx, mode, canvas, frame, ref, rect, frameAlpha=None, refAlpha=None, isAlpha=False, hasExtra=False, clamp=False,
+          premult=False):
+    """inner switch of JXLCodestreamDecoder.blendBuffers (JXLCodestreamDecoder.java:285-422); rect =
+    (h, w, canvas_y, canvas_x, frame_y, frame_x, ref_y, ref_x); returns the updated canvas"""
+    is_int = canvas.dtype == np.int32
+    dt = np.int32 if is_int else np.float32
+    cv = np.array(canvas, dt, order="C", copy=True)
+    fr = np.ascontiguousarray(frame, dt) if frame is not None else None
+    rf = np.ascontiguousarray(ref, dt) if ref is not None else None
+    fa = np.ascontiguousarray(frameAlpha, np.float32) if frameAlpha is not None else None
+    ra = np.ascontiguousarray(refAlpha, np.float32) if refAlpha is not None else None
+    flags = (1 if isAlpha else 0) | (2 if hasExtra else 0) | (4 if clamp else 0) | (8 if premult else 0)
+    r = abi.BlendRect(*[int(v) for v in rect])
+    fh, fw = fr.shape if fr is not None else (fa.shape if fa is not None else (0, 0))
+    rh, rw = rf.shape if rf is not None else (ra.shape if ra is not None else (0, 0))
+    ctx.call("jxl_stage_blend", mode, flags, 1 if is_int else 0, _vp(cv), cv.shape[0], cv.shape[1], _vp(fr), fh, fw,
+             _vp(rf), rh, rw, abi.fptr(fa) if fa is not None else None, abi.fptr(ra) if ra is not None else None, C.byref(r))
+    return cv
+
+
+def transposeBuffer(ctx, src, orientation):
+    """JXLCodestreamDecoder.transposeBuffer (JXLCodestreamDecoder.java:43-184)"""
+    if src.dtype not in (np.int32, np.float32):
+        raise TypeError("int32 or float32 planes")
+    a = np.ascontiguousarray(src)
+    h, w = a.shape
+    out = np.empty((w, h) if orientation > 4 else (h, w), a.dtype)
+    ctx.call("jxl_stage_orient", _vp(a), h, w, orientation, _vp(out))
+    return out
+
+
+def packSamples(ctx, planes, bitDepth, alpha=None, premultiplied=False, taggedDepth=None, bigEndian=False):
+    """PNGWriter ctor tail + writeIDAT sample order (PNGWriter.java:79-111, 191-203): planes = 1 or 3 colour planes
+    (int32 or float32 each), optional alpha plane; returns [h][w][channels] uint8 / uint16"""
+    pl = [np.ascontiguousarray(p) for p in planes] + ([np.ascontiguousarray(alpha)] if alpha is not None else [])
+    h, w = pl[0].shape
+    p = abi.PackParams()
+    p.height, p.width, p.n_color, p.has_alpha = h, w, len(planes), 1 if alpha is not None else 0
+    p.premultiplied, p.bit_depth, p.big_endian = int(bool(premultiplied)), bitDepth, int(bool(bigEndian))
+    for i, a in enumerate(pl):
+        if a.dtype not in (np.int32, np.float32) or a.shape != (h, w):
+            raise TypeError("planes must be int32 or float32 of one shape")
+        p.is_int[i] = 1 if a.dtype == np.int32 else 0
+        p.tagged_depth[i] = (taggedDepth[i] if taggedDepth is not None else bitDepth)
+    out = np.empty((h, w, len(pl)), np.uint8 if bitDepth == 8 else np.uint16)
+    pp = (C.c_void_p * 4)(*([_vp(a) for a in pl] + [None] * (4 - len(pl))))
+    ctx.call("jxl_stage_pack", pp, C.byref(p), _vp(out))
     return out

@@ -773,7 +773,9 @@ jxl_status orc_vardct_frame_run(const orc_vardct_frame* f, void* const out[3]) {
         orc_xyb(buf, (int64_t)n, p->opsin_matrix, p->opsin_bias, p->cbrt_opsin_bias, p->intensity_target);
 
     if ((p->stages & JXL_STAGE_OUT) && (p->transfer != JXL_TRANSFER_NONE || p->out_format != JXL_OUT_F32)) {
-        int maxv = p->out_format == JXL_OUT_U16 ? 65535 : p->out_format == JXL_OUT_U8 ? 255 : 0;
+        /* the interleaved formats (row f3) hold the same samples; the oracle always returns int32 planes */
+        int maxv = (p->out_format == JXL_OUT_U16 || p->out_format == JXL_OUT_RGB16) ? 65535
+                 : (p->out_format == JXL_OUT_U8 || p->out_format == JXL_OUT_RGB8) ? 255 : 0;
         for (int c = 0; c < 3; c++)
             orc_transfer(buf[c], (int64_t)n, p->transfer, maxv, (float*)out[c], (int32_t*)out[c]);
     } else {

@@ -75,6 +75,18 @@ int32_t orc_squeezed_shapes(const int32_t* widths, const int32_t* heights, int32
 jxl_status orc_modular_apply(const jxl_channel* chans, int32_t n_chans, const jxl_squeeze_param* sp, int32_t n_sp,
                              int32_t rct_type, int32_t rct_begin, jxl_channel* out, int32_t n_out);
 
+/* rows f4 / f3 (jxl_oracle_post.c): same argument meaning as the jxl_stage_* entries of the same name */
+void orc_chroma_upsample(const float* in, int h, int w, int x_shift, int y_shift, float* out);
+jxl_status orc_upsampling_weights(int k, const float* packed, float* out);
+void orc_upsample(const float* in, int h, int w, int k, const float* weights, float* out);
+void orc_noise_init(int h, int w, int group_dim, uint64_t seed0, int colors, float* const out[3]);
+void orc_noise_add(float* const planes[3], const float* const noise[3], int64_t n, const float lut[8], float base_corr_x,
+                   float base_corr_b);
+jxl_status orc_blend(int mode, uint32_t flags, int is_int, void* canvas, int ch, int cw, const void* frame, int fh, int fw,
+                     const void* ref, int rh, int rw, const float* frame_alpha, const float* ref_alpha, const jxl_blend_rect* r);
+jxl_status orc_orient(const void* in, int h, int w, int orientation, void* out);
+jxl_status orc_pack(const void* const planes[4], const jxl_pack_params* p, void* out);
+
 /* TEST-ONLY forward squeeze steps (the reference has no encoder; derived from the inverse,
  * SURVEY.md Appendix A.11): split in (h x w) into avg and res. */
 void orc_fwd_hsqueeze(const int32_t* in, int h, int w, int32_t* avg, int32_t* res);

@@ -18,8 +18,8 @@ _SO = os.path.join(_HERE, "libjxl_oracle.so")
 
 def build(force=False):
     """compile the oracle with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "jxl_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("jxl_oracle.c", "jxl_oracle_post.c", "jxl_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -48,6 +48,8 @@ def lib():
         L.orc_modular_apply.restype = C.c_int32
         L.orc_default_squeeze_params.restype = C.c_int32
         L.orc_squeezed_shapes.restype = C.c_int32
+        for f in ("orc_upsampling_weights", "orc_blend", "orc_orient", "orc_pack"):
+            getattr(L, f).restype = C.c_int32
         _lib = L
     return _lib
 
@@ -314,3 +316,94 @@ def inverse_shapes(shapes, sp):
                 shapes[c] = (shapes[c][0] + shapes[r][0], shapes[c][1])
         del shapes[offset:offset + num]
     return shapes
+
+
+# ---- rows f4 / f3 (jxl_oracle_post.c) ----------------------------------------------------------------------
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def chroma_upsample(channel, x_shift, y_shift):
+    a = np.ascontiguousarray(channel, np.float32)
+    h, w = a.shape
+    out = np.empty((h << y_shift, w << x_shift), np.float32)
+    lib().orc_chroma_upsample(abi.fptr(a), C.c_int(h), C.c_int(w), C.c_int(x_shift), C.c_int(y_shift), abi.fptr(out))
+    return out
+
+
+def upsampling_weights(k, packed):
+    packed = np.ascontiguousarray(packed, np.float32)
+    out = np.empty((k, k, 5, 5), np.float32)
+    st = lib().orc_upsampling_weights(C.c_int(k), abi.fptr(packed), abi.fptr(out))
+    assert st == 0, st
+    return out
+
+
+def upsample(channel, k, weights):
+    a = np.ascontiguousarray(channel, np.float32)
+    wts = np.ascontiguousarray(weights, np.float32)
+    h, w = a.shape
+    out = np.empty((h * k, w * k), np.float32)
+    lib().orc_upsample(abi.fptr(a), C.c_int(h), C.c_int(w), C.c_int(k), abi.fptr(wts), abi.fptr(out))
+    return out
+
+
+def noise_init(h, w, seed0, group_dim=256, colors=3):
+    out = np.empty((colors, h, w), np.float32)
+    pp = (C.POINTER(C.c_float) * 3)(*[abi.fptr(out[c]) for c in range(colors)])
+    lib().orc_noise_init(C.c_int(h), C.c_int(w), C.c_int(group_dim), C.c_uint64(seed0 & 0xFFFFFFFFFFFFFFFF), C.c_int(colors), pp)
+    return out
+
+
+def noise_add(planes, noise, lut, base_corr_x, base_corr_b):
+    out = np.array(planes, np.float32, order="C", copy=True)
+    nz = np.ascontiguousarray(noise, np.float32)
+    lut = np.ascontiguousarray(lut, np.float32)
+    pp = (C.POINTER(C.c_float) * 3)(*[abi.fptr(out[c]) for c in range(3)])
+    pn = (C.POINTER(C.c_float) * 3)(*[abi.fptr(nz[c]) for c in range(3)])
+    lib().orc_noise_add(pp, pn, C.c_int64(out[0].size), abi.fptr(lut), C.c_float(base_corr_x), C.c_float(base_corr_b))
+    return out
+
+
+def blend(mode, canvas, frame, ref, rect, frame_alpha=None, ref_alpha=None, is_alpha=False, has_extra=False, clamp=False,
+          premult=False):
+    is_int = canvas.dtype == np.int32
+    dt = np.int32 if is_int else np.float32
+    cv = np.array(canvas, dt, order="C", copy=True)
+    fr = np.ascontiguousarray(frame, dt) if frame is not None else None
+    rf = np.ascontiguousarray(ref, dt) if ref is not None else None
+    fa = np.ascontiguousarray(frame_alpha, np.float32) if frame_alpha is not None else None
+    ra = np.ascontiguousarray(ref_alpha, np.float32) if ref_alpha is not None else None
+    flags = (1 if is_alpha else 0) | (2 if has_extra else 0) | (4 if clamp else 0) | (8 if premult else 0)
+    r = abi.BlendRect(*[int(v) for v in rect])
+    fh, fw = fr.shape if fr is not None else (fa.shape if fa is not None else (0, 0))
+    rh, rw = rf.shape if rf is not None else (ra.shape if ra is not None else (0, 0))
+    st = lib().orc_blend(C.c_int(mode), C.c_uint32(flags), C.c_int(1 if is_int else 0), _vp(cv), C.c_int(cv.shape[0]),
+                         C.c_int(cv.shape[1]), _vp(fr), C.c_int(fh), C.c_int(fw), _vp(rf), C.c_int(rh), C.c_int(rw),
+                         abi.fptr(fa) if fa is not None else None, abi.fptr(ra) if ra is not None else None, C.byref(r))
+    return st, cv
+
+
+def orient(src, orientation):
+    a = np.ascontiguousarray(src)
+    h, w = a.shape
+    out = np.empty((w, h) if orientation > 4 else (h, w), a.dtype)
+    st = lib().orc_orient(_vp(a), C.c_int(h), C.c_int(w), C.c_int(orientation), _vp(out))
+    assert st == 0, st
+    return out
+
+
+def pack(planes, bit_depth, alpha=None, premultiplied=False, tagged_depth=None, big_endian=False):
+    pl = [np.ascontiguousarray(p) for p in planes] + ([np.ascontiguousarray(alpha)] if alpha is not None else [])
+    h, w = pl[0].shape
+    p = abi.PackParams()
+    p.height, p.width, p.n_color, p.has_alpha = h, w, len(planes), 1 if alpha is not None else 0
+    p.premultiplied, p.bit_depth, p.big_endian = int(bool(premultiplied)), bit_depth, int(bool(big_endian))
+    for i, a in enumerate(pl):
+        p.is_int[i] = 1 if a.dtype == np.int32 else 0
+        p.tagged_depth[i] = (tagged_depth[i] if tagged_depth is not None else bit_depth)
+    out = np.empty((h, w, len(pl)), np.uint8 if bit_depth == 8 else np.uint16)
+    pp = (C.c_void_p * 4)(*([_vp(a) for a in pl] + [None] * (4 - len(pl))))
+    st = lib().orc_pack(pp, C.byref(p), _vp(out))
+    assert st == 0, st
+    return out

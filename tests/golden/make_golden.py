@@ -48,6 +48,45 @@ def npz_to_frame(z):
                 coeff=np.ascontiguousarray(z["coeff"]), width=int(z["width"]), height=int(z["height"]))
 
 
+def post_inputs():
+    """inputs of the rows f4 / f3 fixture (finite values only, so every expected bit is platform-independent)"""
+    rng = np.random.default_rng(4242)
+    d = dict(plane=(rng.standard_normal((20, 28)) * 0.3 + 0.4).astype(np.float32),
+             up_packed2=(rng.standard_normal(15) * 0.2).astype(np.float32),
+             up_packed4=(rng.standard_normal(55) * 0.2).astype(np.float32),
+             xyb=(rng.random((3, 20, 28)) * 0.8).astype(np.float32), noise_lut=(rng.random(8) * 0.9).astype(np.float32),
+             frame=rng.random((16, 30)).astype(np.float32), frame_alpha=(rng.random((16, 30)) * 1.3 - 0.1).astype(np.float32),
+             ref=rng.random((20, 28)).astype(np.float32), ref_alpha=(rng.random((20, 28)) * 0.9 + 0.05).astype(np.float32),
+             ints=rng.integers(-50, 5000, (3, 20, 28)).astype(np.int32))
+    return d
+
+
+POST_RECT = (12, 20, 4, 5, 2, 6, 4, 5)
+POST_SEED = (5 << 32) | 11
+
+
+def post_vectors(d=None):
+    d = dict(d or post_inputs())
+    d["chroma_11"] = orc.chroma_upsample(d["plane"], 1, 1)
+    d["chroma_20"] = orc.chroma_upsample(d["plane"], 2, 0)
+    for k in (2, 4):
+        w = orc.upsampling_weights(k, d["up_packed%d" % k])
+        d["up%d" % k] = orc.upsample(d["plane"], k, w)
+    nz = orc.noise_init(20, 28, POST_SEED, group_dim=16)
+    d["noise"] = nz
+    d["noise_added"] = orc.noise_add(d["xyb"], nz, d["noise_lut"], 0.0, 1.0)
+    for mode, kw in ((abi.BLEND_ADD, {}), (abi.BLEND_MULT, dict(clamp=True)), (abi.BLEND_BLEND, dict(has_extra=True, clamp=True)),
+                     (abi.BLEND_BLEND, dict(has_extra=True, premult=True)), (abi.BLEND_MULADD, dict(has_extra=True))):
+        st, out = orc.blend(mode, d["ref"], d["frame"], d["ref"], POST_RECT, frame_alpha=d["frame_alpha"], ref_alpha=d["ref_alpha"], **kw)
+        assert st == 0
+        d["blend_%d_%d" % (mode, 1 if kw.get("premult") else 0)] = out
+    d["orient6"] = orc.orient(d["ints"][0], 6)
+    d["orient7"] = orc.orient(d["plane"], 7)
+    d["pack_rgb8"] = orc.pack(list(d["xyb"]), 8)
+    d["pack_rgba16be"] = orc.pack(list(d["ints"]), 16, alpha=d["ref_alpha"], premultiplied=True, tagged_depth=[12, 12, 12, 8], big_endian=True)
+    return d
+
+
 def main():
     # 1. VarDCT frame, every varblock type up to 64x64, aligned and unaligned tilings, all stage prefixes
     for name, aligned, seed in (("vardct_aligned", True, 2024), ("vardct_unaligned", False, 2025)):
@@ -88,6 +127,7 @@ def main():
     st["idct_32x64_t"] = orc.idct2d(x, transposed=True)
     st["fdct_32x64"] = orc.fdct2d(x)
     np.savez_compressed(os.path.join(HERE, "stages.npz"), **st)
+    np.savez_compressed(os.path.join(HERE, "post.npz"), **post_vectors())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -52,6 +52,16 @@ def test_oracle_reproduces_modular_golden(orc):
         assert_bits_equal(o, z["out%d" % i], "modular out%d" % i)
 
 
+def test_oracle_reproduces_post_golden(orc):
+    from make_golden import post_vectors
+    z = load("post")
+    again = post_vectors({k: z[k] for k in ("plane", "up_packed2", "up_packed4", "xyb", "noise_lut", "frame", "frame_alpha", "ref",
+                                            "ref_alpha", "ints")})
+    assert set(again) == set(z.files)
+    for k in z.files:
+        assert_bits_equal(again[k], z[k], "post " + k)
+
+
 # ---- GPU -----------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", VARDCT)
@@ -94,3 +104,27 @@ def test_hip_reproduces_modular_golden(ctx):
     assert len(out) == 3
     for i, o in enumerate(out):
         assert_bits_equal(o, z["out%d" % i], "modular out%d" % i)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_post_golden(ctx):
+    """rows f4 / f3 against the committed fixture (no oracle involved)"""
+    from make_golden import POST_RECT, POST_SEED
+    z = load("post")
+    pl = z["plane"]
+    assert_bits_equal(host.invertSubsampling(ctx, pl, 1, 1), z["chroma_11"], "chroma 1,1")
+    assert_bits_equal(host.invertSubsampling(ctx, pl, 2, 0), z["chroma_20"], "chroma 2,0")
+    for k in (2, 4):
+        assert_bits_equal(host.performUpsampling(ctx, pl, k, host.getUpWeights(k, z["up_packed%d" % k])), z["up%d" % k], "up%d" % k)
+    nz = host.initializeNoise(ctx, 20, 28, POST_SEED, groupDim=16)
+    assert_bits_equal(nz, z["noise"], "noise")
+    assert_bits_equal(host.synthesizeNoise(ctx, z["xyb"], nz, z["noise_lut"], 0.0, 1.0), z["noise_added"], "noise added")
+    for mode, kw in ((abi.BLEND_ADD, {}), (abi.BLEND_MULT, dict(clamp=True)), (abi.BLEND_BLEND, dict(hasExtra=True, clamp=True)),
+                     (abi.BLEND_BLEND, dict(hasExtra=True, premult=True)), (abi.BLEND_MULADD, dict(hasExtra=True))):
+        got = host.blend(ctx, mode, z["ref"], z["frame"], z["ref"], POST_RECT, frameAlpha=z["frame_alpha"], refAlpha=z["ref_alpha"], **kw)
+        assert_bits_equal(got, z["blend_%d_%d" % (mode, 1 if kw.get("premult") else 0)], "blend %d" % mode)
+    assert_bits_equal(host.transposeBuffer(ctx, z["ints"][0], 6), z["orient6"], "orient 6")
+    assert_bits_equal(host.transposeBuffer(ctx, pl, 7), z["orient7"], "orient 7")
+    assert_bits_equal(host.packSamples(ctx, list(z["xyb"]), 8), z["pack_rgb8"], "pack rgb8")
+    got = host.packSamples(ctx, list(z["ints"]), 16, alpha=z["ref_alpha"], premultiplied=True, taggedDepth=[12, 12, 12, 8], bigEndian=True)
+    assert_bits_equal(got, z["pack_rgba16be"], "pack rgba16be")
