@@ -15,7 +15,7 @@ from . import abi
 
 F = np.float32
 
-MODE_HORNUSS, MODE_DCT2, MODE_DCT4, MODE_DCT4_8, MODE_AFV, MODE_DCT = 1, 2, 3, 4, 5, 6
+MODE_HORNUSS, MODE_DCT2, MODE_DCT4, MODE_DCT4_8, MODE_AFV, MODE_DCT, MODE_RAW = 1, 2, 3, 4, 5, 6, 7
 
 _SEQ_A = [-1.025, -0.78, -0.65012, -0.19041574084286472, -0.20819395464, -0.421064, -0.32733845535848671]
 _SEQ_B = [-0.3041958212306401, -0.3633036457487539, -0.35660379990111464, -0.3443074455424403,
@@ -211,12 +211,15 @@ def generate_weights(params=None):
                 w[1, 0] = F(w[1, 0] / F(prm["par"][c][0]))
             elif mode == MODE_AFV:
                 w = _afv_weights(prm, c)
+            elif mode == MODE_RAW:  # HFGlobal.java:407-416: the table itself times the denominator, no reciprocal
+                w = (np.array(prm["par"][c], F).reshape(mh, mw) * F(prm.get("denominator", 1.0))).astype(F)
             else:
                 raise ValueError("unsupported quant-weight mode %r" % mode)
             assert w.shape == (mh, mw)
-            if not (np.all(w > 0) and np.all(np.isfinite(w))):
-                raise ValueError("Negative or infinite weight: %d, %d" % (idx, c))  # HFGlobal.java:425-426
-            w = (F(1.0) / w).astype(F)
+            if mode != MODE_RAW:
+                if not (np.all(w > 0) and np.all(np.isfinite(w))):
+                    raise ValueError("Negative or infinite weight: %d, %d" % (idx, c))  # HFGlobal.java:425-426
+                w = (F(1.0) / w).astype(F)
             offs[idx * 3 + c] = pos
             chunks.append(w.ravel())
             pos += w.size
