@@ -1,0 +1,223 @@
+"""Row f2: the C++ bitstream front-end and the JXLDecoder host layer on REAL .jxl files (tests/golden/samples/, copies of
+the reference's samples/ data files).
+
+CPU: every sample parses with valid ANS final states; decoded pixels through the oracle-backed backend are pinned by
+CRCs (regression) and by structural properties (white.jxl is white, art.jxl is the 128x128 8-bit RGB image of config C1).
+GPU: the same files through the device library give bit-identical pixels to the oracle-backed decode -- parity of the
+hot path on real varblock statistics, real LF images and real modular streams."""
+import io
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from jxlatte_amd import frontend
+from jxlatte_amd.decoder import JXLDecoder, PNGWriter, UnsupportedOperationException
+
+SAMPLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "samples")
+ALL = ["art", "quilt", "white", "blendmodes_5", "wb-rainbow", "lenna", "bbb", "patches-lossless", "bench"]
+DECODABLE = ["art", "quilt", "white", "blendmodes_5", "lenna", "bbb", "patches-lossless", "bench"]
+
+
+def path(name):
+    return os.path.join(SAMPLES, name + ".jxl")
+
+
+@pytest.fixture(scope="module")
+def oracle_backend(orc):
+    from oracle.pybackend import OracleBackend
+    return OracleBackend()
+
+
+def oracle_hooks(orc):
+    return (lambda ins, steps, shapes: orc.modular_apply(ins, steps, rct_type=-1, out_shapes=shapes),
+            lambda a, b, c, t: orc.rct(np.stack([a, b, c]), t))
+
+
+def read_png(data):
+    pos, idat, hdr = 8, b"", None
+    while pos < len(data):
+        n = struct.unpack(">I", data[pos:pos + 4])[0]
+        tag, body = data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) & 0xffffffff == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, bd, cm = hdr[:4]
+    ch = {0: 1, 2: 3, 4: 2, 6: 4}[cm]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch * (bd // 8))
+    assert not raw[:, 0].any()
+    px = raw[:, 1:]
+    return (px.reshape(h, w, ch) if bd == 8 else px.reshape(h, w, ch, 2).astype(np.uint16) @ np.array([256, 1], np.uint16)), bd
+
+
+# ---- front-end only ------------------------------------------------------------------------------------------
+EXPECT_HEADERS = {  # name: (width, height, bits, extra channels, xyb, orientation, frames, first frame encoding)
+    "art": (128, 128, 8, 0, 0, 1, 1, 1), "quilt": (1024, 1024, 8, 0, 0, 1, 1, 1), "white": (320, 240, 8, 0, 1, 1, 1, 0),
+    "blendmodes_5": (1024, 1024, 12, 1, 0, 1, 5, 1), "wb-rainbow": (2048, 1152, 9, 1, 0, 1, 5, 1),
+    "lenna": (512, 512, 8, 0, 1, 1, 1, 0), "bbb": (1280, 720, 8, 0, 1, 1, 1, 0),
+    "patches-lossless": (1600, 1096, 8, 1, 0, 1, 2, 1), "bench": (500, 606, 8, 0, 0, 5, 1, 0),
+}
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_frontend_parses_sample(orc, name):
+    """every section of every frame decodes and every ANS stream ends in its initial state (the front-end checks
+    EntropyStream.validateFinalState after each stream and fails otherwise)"""
+    fe = frontend.Frontend(open(path(name), "rb").read())
+    im = fe.image
+    sq, rct = oracle_hooks(orc)
+    frames = []
+    while True:
+        fr = fe.next_frame(sq, rct)
+        if fr is None:
+            break
+        frames.append((fr.encoding, fr.width, fr.height, fr.num_groups))
+    w, h, bits, extra, xyb, orient, nframes, enc0 = EXPECT_HEADERS[name]
+    assert (im.width, im.height, im.bits_per_sample, im.num_extra, im.xyb_encoded, im.orientation) == (w, h, bits, extra, xyb, orient)
+    assert len(frames) == nframes and frames[0][0] == enc0
+
+
+def test_frontend_boundary_tensors_of_lenna(orc):
+    fe = frontend.Frontend(open(path("lenna"), "rb").read())
+    fr = fe.next_frame(None, None)  # a VarDCT frame needs no modular hooks
+    assert (fr.width, fr.height, fr.num_groups, fr.num_lf_groups, fr.num_passes) == (512, 512, 4, 1, 1)
+    g = fe.lfgroup(0)
+    assert g["dct_select"].shape == (64, 64) and not (g["dct_select"] == 255).any()  # every cell is covered by a varblock
+    # the block list reproduces the map: each listed corner carries its own type and the footprints tile the LF group
+    from jxlatte_amd import abi
+    cover = np.zeros((64, 64), np.int32)
+    for (y, x) in g["block_yx"]:
+        t = g["dct_select"][y, x]
+        hh, ww = abi.TRANSFORM_TYPES[t][5] >> 3, abi.TRANSFORM_TYPES[t][6] >> 3
+        assert (g["dct_select"][y:y + hh, x:x + ww] == t).all()
+        cover[y:y + hh, x:x + ww] += 1
+    assert (cover == 1).all()
+    assert 0 <= g["sharpness"].min() and g["sharpness"].max() <= 7 and g["hf_mul"].min() >= 1
+    q = fe.coeffs(0, 0)
+    assert [a.shape for a in q] == [(256, 256)] * 3 and sum(int(np.count_nonzero(a)) for a in q) > 1000
+    # LLF corners of the coefficient planes are never written by the HF decoder
+    y, x = g["block_yx"][0]
+    assert all(a[8 * y, 8 * x] == 0 for a in q)
+
+
+def test_frontend_rejects_garbage():
+    with pytest.raises(frontend.FrontendError):
+        frontend.Frontend(b"\xff\x0b" + bytes(30))
+    good = open(path("lenna"), "rb").read()
+    fe = frontend.Frontend(good[:2000])  # header parses, the frame payload is truncated
+    with pytest.raises(frontend.FrontendError):
+        fe.next_frame(None, None)
+
+
+def test_frame_level_modular_needs_hooks():
+    """no CPU fallback for the frame-level inverse Squeeze / RCT: without hooks the front-end refuses"""
+    for name in ("art", "quilt"):  # art.jxl: frame-level RCT; quilt.jxl: frame-level Squeeze (16 steps)
+        fe = frontend.Frontend(open(path(name), "rb").read())
+        with pytest.raises(frontend.FrontendError, match="device hook"):
+            fe.next_frame(None, None)
+
+
+# ---- decoder through the oracle backend (CPU) --------------------------------------------------------------------
+def decode(name, backend):
+    dec = JXLDecoder(path(name), backend=backend)
+    return dec, dec.decode()
+
+
+def test_c1_art_jxl_to_png(oracle_backend):
+    """config C1: samples/art.jxl -> a 128x128 8-bit RGB PNG"""
+    _, img = decode("art", oracle_backend)
+    assert (img.getWidth(), img.getHeight(), img.getColorChannelCount(), img.hasAlpha()) == (128, 128, 3, False)
+    buf = io.BytesIO()
+    PNGWriter(img).write(buf)
+    px, bd = read_png(buf.getvalue())
+    assert px.shape == (128, 128, 3) and bd == 8
+    # lossless modular, sRGB tagged, 8 bit: the PNG samples are the decoded integers themselves
+    for c in range(3):
+        assert np.array_equal(px[..., c], np.clip(img.buffer[c], 0, 255))
+    assert len(np.unique(px.reshape(-1, 3), axis=0)) > 50  # a picture, not a flat field
+
+
+def test_white_jxl_is_white(oracle_backend):
+    _, img = decode("white", oracle_backend)
+    buf = io.BytesIO()
+    PNGWriter(img).write(buf)
+    px, _ = read_png(buf.getvalue())
+    assert px.shape == (240, 320, 3) and px.min() >= 254
+
+
+CRCS = {}
+
+
+def pixel_crc(img):
+    c = 0
+    for b in img.buffer:
+        a = np.ascontiguousarray(b)
+        if a.dtype == np.float32:
+            a = np.where(np.isnan(a), np.float32(0), a)
+        c = zlib.crc32(a.tobytes(), c)
+    return c
+
+
+@pytest.mark.parametrize("name", DECODABLE)
+def test_decode_sample_oracle_backend(oracle_backend, name):
+    dec, img = decode(name, oracle_backend)
+    w, h = EXPECT_HEADERS[name][:2]
+    if EXPECT_HEADERS[name][5] > 4:
+        w, h = h, w
+    assert (img.getWidth(), img.getHeight()) == (w, h)
+    for b in img.buffer:
+        assert b.shape == (h, w)
+        if b.dtype == np.float32:
+            assert np.isfinite(b).all()
+    fix = os.path.join(SAMPLES, "pixel_crc.txt")
+    known = dict(l.split() for l in open(fix)) if os.path.exists(fix) else {}
+    crc = "%08x" % pixel_crc(img)
+    if name in known:
+        assert known[name] == crc, "decoded pixels of %s changed" % name
+    else:  # first run in the build container records the value (committed afterwards)
+        with open(fix, "a") as f:
+            f.write("%s %s\n" % (name, crc))
+    if name in ("lenna", "bbb"):  # photographic content: natural-image statistics, no blocking garbage
+        buf = io.BytesIO()
+        PNGWriter(img).write(buf)
+        px, _ = read_png(buf.getvalue())
+        g = px.astype(np.float32).mean(-1)
+        assert 40 < g.mean() < 215 and g.std() > 20
+        # neighbouring pixels are strongly correlated in a correctly reconstructed photo
+        assert np.corrcoef(g[:, :-1].ravel(), g[:, 1:].ravel())[0, 1] > 0.97
+
+
+def test_unsupported_is_reported_not_faked(oracle_backend):
+    with pytest.raises(UnsupportedOperationException):
+        decode("wb-rainbow", oracle_backend)  # splines
+
+
+# ---- device vs oracle on real files (GPU) --------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def device_backend():
+    from jxlatte_amd.decoder import DeviceBackend
+    b = DeviceBackend(0)
+    yield b
+    b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DECODABLE)
+def test_device_decode_matches_oracle_decode(device_backend, oracle_backend, name):
+    _, got = decode(name, device_backend)
+    _, exp = decode(name, oracle_backend)
+    assert len(got.buffer) == len(exp.buffer)
+    for c, (a, b) in enumerate(zip(got.buffer, exp.buffer)):
+        assert_bits_equal(a, b, "%s channel %d" % (name, c))
+    ga, gb = io.BytesIO(), io.BytesIO()
+    PNGWriter(got).write(ga)
+    PNGWriter(exp).write(gb)
+    pa, _ = read_png(ga.getvalue())
+    pb, _ = read_png(gb.getvalue())
+    assert np.abs(pa.astype(np.int32) - pb.astype(np.int32)).max() <= 1  # transfer stage: 1 ulp -> at most one code value
