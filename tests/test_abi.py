@@ -25,6 +25,18 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.jxl_version()
 
 
+def test_frontend_library_exports_every_declared_symbol():
+    from jxlatte_amd import frontend
+    lib = frontend.load()
+    header = open(os.path.join(ROOT, "include", "jxlatte_frontend.h")).read()
+    declared = set(re.findall(r"\b(jxf_[a-z0-9_]+)\s*\(", header)) - {"jxf_hooks"}
+    assert declared == set(frontend.SIGNATURES.keys())
+    assert not [n for n in declared if not hasattr(lib, n)]
+    # ctypes mirrors have the C layout (all 4-byte members except the flags word and pointers)
+    assert C.sizeof(frontend.ImageInfo) == 4 * (9 + 6 + 2 + 6 + 4 + 9 + 3 + 3 + 1 + 2 + 3 + 5 * 16)
+    assert C.sizeof(frontend.Chan) == 24 and C.sizeof(frontend.SqueezeStep) == 16
+
+
 def test_no_device_fails_loudly():
     """no GPU in the build container: creating a context must fail with a device error, never fall back"""
     import torch
