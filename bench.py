@@ -32,7 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="vardct4k", choices=["vardct4k", "vardct8k_pq", "modular1080p", "modular8k"])
+    ap.add_argument("--workload", default="vardct4k", choices=["vardct4k", "vardct8k_pq", "modular1080p", "modular8k", "jxlfile"])
+    ap.add_argument("--input", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "samples", "bbb.jxl"),
+                    help="--workload jxlfile: a VarDCT .jxl file parsed by the C++ front-end (real varblock statistics)")
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=2, help="distinct synthetic frames generated per rank (the rest reuse them)")
     ap.add_argument("--mix", default="default")
@@ -83,6 +85,7 @@ def main():
 
     W, H = (3840, 2160) if args.workload == "vardct4k" else (7680, 4320)
     fpg = args.frames_per_gpu
+    real_stats = None
     kw = dict(epf_iters=args.epf_iters)
     if args.workload == "vardct8k_pq":
         kw.update(transfer=abi.TRANSFER_PQ, out_format=abi.OUT_U16, opsin_matrix=synth.bt2100_opsin_matrix(), intensity_target=10000.0)
@@ -90,7 +93,7 @@ def main():
     # ---- synthetic inputs -> HBM (untimed)
     t0 = time.time()
     distinct = []
-    for i in range(min(args.distinct_frames, fpg)):
+    for i in range(0 if args.workload == "jxlfile" else min(args.distinct_frames, fpg)):
         seed = 1234 if (world == 1 and fpg == 1) else 1000 + rank * fpg + i
         distinct.append(synth.make_vardct_frame(W, H, seed=seed, mix=args.mix, **kw))
     ctxs, frames = [], []
@@ -99,12 +102,18 @@ def main():
         if args.streams == 1 and ctxs:
             c.call("jxl_ctx_set_stream", ctxs[0].stream)
         ctxs.append(c)
-        frames.append(host.Frame.from_synth(c, distinct[i % len(distinct)], stages=args.stages))
+        if args.workload == "jxlfile":
+            from jxlatte_amd.decoder import load_vardct_frame
+            fr_, real_stats = load_vardct_frame(args.input, c)
+            W, H = real_stats["padded_width"], real_stats["padded_height"]
+            frames.append(fr_)
+        else:
+            frames.append(host.Frame.from_synth(c, distinct[i % len(distinct)], stages=args.stages))
     gen_s = time.time() - t0
     npx = W * H
     lib = _lib.load()
 
-    if args.verify and rank == 0:
+    if args.verify and rank == 0 and distinct:
         from oracle import pyoracle as orc
         got = frames[0].decodeFrame()
         exp = orc.vardct_frame(distinct[0], threads=os.cpu_count())
@@ -202,7 +211,7 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (restoration + colour stage) and of the whole path
-    out_bytes_px = 12.0 if args.workload == "vardct4k" else 6.0
+    out_bytes_px = 6.0 if args.workload == "vardct8k_pq" else 12.0
     side = 21.0 / 64.0  # per-pixel share of the 8x8-cell side info
     path_bytes = (12.0 + out_bytes_px + side) * npx + 1.58e6  # whole path, algorithmic (24.5 B/px for f32 out)
     rest_bytes = (12.0 + out_bytes_px + 8.0 / 64.0) * npx     # restore stage: planes in + planes out + hfMul/sharpness
@@ -230,7 +239,7 @@ def main():
     }
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and distinct:
         # bounded sample (~10-30 s of CPU work): one frame of the same workload on all host cores, plus a
         # quarter-size frame of the same generator on ONE core (the reference's transform stage is single-threaded)
         from oracle import pyoracle as orc
@@ -253,11 +262,13 @@ def main():
         "metric": "Mpixels/s decoded (VarDCT 4K frame) at 1/2/4/8 MI355X vs host-CPU jxlatte",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" if distinct else "real bitstream %s (parsed by the C++ front-end)" % os.path.basename(args.input),
         "config": {"workload": "%s: %d independent %dx%d VarDCT frames per GPU (mix=%s, Gab + EPF x%d + XYB, %s out), inputs resident in HBM"
-                               % (args.workload, fpg, W, H, args.mix, args.epf_iters, "f32" if out_bytes_px == 12.0 else "PQ u16"),
-                   "frames_per_gpu": fpg, "distinct_frames": len(distinct), "streams": args.streams if args.streams else fpg,
-                   "varblock_area_share": synth.type_histogram(distinct[0]), "kernel_launches_per_frame": launches,
+                               % (args.workload, fpg, W, H, args.mix if distinct else "as coded", real_stats["epf_iters"] if real_stats else args.epf_iters,
+                                  "f32" if out_bytes_px == 12.0 else "PQ u16"),
+                   "frames_per_gpu": fpg, "distinct_frames": len(distinct) or 1, "streams": args.streams if args.streams else fpg,
+                   "varblock_area_share": synth.type_histogram(distinct[0]) if distinct else real_stats["varblocks"],
+                   "kernel_launches_per_frame": launches,
                    "single_frame_ms": round(single_ms, 4),
                    "single_frame_Mpx_s": round(npx / single_ms / 1e3, 1), "input_gen_s": round(gen_s, 1)},
         "roofline": roofline,

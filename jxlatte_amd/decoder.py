@@ -435,6 +435,13 @@ class JXLDecoder:
         return hfglobal.generate_weights(params)
 
     def _vardct_frame(self, fr, fuse_xyb):
+        p, weights, woffs, lfgroups, groups, hist = self._vardct_inputs(fr, fuse_xyb)
+        planes = self.backend.vardct(p, weights, woffs, lfgroups, groups())
+        self.stats[-1]["varblocks"] = {abi.TT_NAME[t]: int(n) for t, n in enumerate(hist) if n}
+        return [np.ascontiguousarray(planes[c]) for c in range(3)]
+
+    def _vardct_inputs(self, fr, fuse_xyb):
+        """the boundary tensors of one VarDCT frame: (jxl_vardct_params, weights, offsets, LF groups, group iterator)"""
         info, fe = self.info, self.fe
         if any(fr.jpeg_up_y) or any(fr.jpeg_up_x):
             raise UnsupportedOperationException("chroma-subsampled VarDCT frames (jpegUpsampling != 0)")
@@ -482,9 +489,7 @@ class JXLDecoder:
             for pass_ in range(fr.num_passes):
                 for grp in range(fr.num_groups):
                     yield pass_, grp, fe.coeffs(pass_, grp)
-        planes = self.backend.vardct(p, weights, woffs, lfgroups, groups())
-        self.stats[-1]["varblocks"] = {abi.TT_NAME[t]: int(n) for t, n in enumerate(hist) if n}
-        return [np.ascontiguousarray(planes[c]) for c in range(3)]
+        return p, weights, woffs, lfgroups, groups, hist
 
     def _modular_buffers(self, fr, buffers, colors):
         """modular channels -> frame buffers (Frame.decodeFrame :430-455)"""
@@ -784,3 +789,37 @@ class PNGWriter:
         raw = np.concatenate([np.zeros((self.height, 1), np.uint8), rows], axis=1).tobytes()  # filter type 0 per row
         out.write(self._chunk(b"IDAT", zlib.compress(raw, self.deflateLevel)))
         out.write(self._chunk(b"IEND", b""))
+
+
+def load_vardct_frame(source, ctx, transfer=abi.TRANSFER_NONE, out_format=abi.OUT_F32):
+    """Parse the first frame of a VarDCT .jxl file with the front-end and stage it in a host.Frame on `ctx` (inputs
+    resident, nothing run yet): the real-bitstream workload of bench.py. Returns (host.Frame, stats dict)."""
+    from . import host
+    if isinstance(source, (bytes, bytearray)):
+        data = bytes(source)
+    else:
+        with open(source, "rb") as f:
+            data = f.read()
+    dec = JXLDecoder.__new__(JXLDecoder)
+    dec.fe = frontend.Frontend(data)
+    dec.info = dec.fe.image
+    dec.backend = None
+    fr = dec.fe.next_frame(None, None)
+    if fr is None or fr.encoding != VARDCT:
+        raise ValueError("first frame is not a VarDCT frame")
+    p, weights, woffs, lfgroups, groups, hist = dec._vardct_inputs(fr, bool(dec.info.xyb_encoded))
+    if transfer != abi.TRANSFER_NONE or out_format != abi.OUT_F32:
+        p.stages |= abi.STAGE_OUT
+        p.transfer, p.out_format = transfer, out_format
+    hf = host.Frame(ctx, p, weights, woffs)
+    for g in lfgroups:
+        hf.setLFGroup(g)
+        if g.get("lf_quant") is not None:
+            hf.setLFGroupQuant(g["lfg_y"], g["lfg_x"], np.ascontiguousarray(np.stack(g["lf_quant"]), np.int32), g["scaled_dequant"],
+                               g["extra_precision"], g["x_factor_lf"], g["b_factor_lf"], g["adaptive_smoothing"])
+    for pass_, grp, q in groups():
+        hf.putGroup(pass_, grp, q)
+    stats = dict(width=fr.width, height=fr.height, padded_width=fr.padded_width, padded_height=fr.padded_height, groups=fr.num_groups,
+                 passes=fr.num_passes, epf_iters=fr.epf_iters, gab=fr.gab,
+                 varblocks={abi.TT_NAME[t]: int(n) for t, n in enumerate(hist) if n})
+    return hf, stats

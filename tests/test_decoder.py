@@ -221,3 +221,21 @@ def test_device_decode_matches_oracle_decode(device_backend, oracle_backend, nam
     pa, _ = read_png(ga.getvalue())
     pb, _ = read_png(gb.getvalue())
     assert np.abs(pa.astype(np.int32) - pb.astype(np.int32)).max() <= 1  # transfer stage: 1 ulp -> at most one code value
+
+
+# ---- large reference samples (not committed: tests/golden/samples_large/ is git-ignored but travels with gpurun) -------
+LARGE = os.path.join(os.path.dirname(SAMPLES), "samples_large")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sollevante-hdr", "george-tiled"])
+def test_device_decode_matches_oracle_decode_large(device_backend, oracle_backend, name):
+    """4K HDR VarDCT (135 groups, 4 LF groups, BT.2100 PQ) and a 135-frame tiled 4K image blended onto one canvas"""
+    p = os.path.join(LARGE, name + ".jxl")
+    if not os.path.exists(p):
+        pytest.skip("large sample not present (kept out of the repository)")
+    got = JXLDecoder(p, backend=device_backend).decode()
+    exp = JXLDecoder(p, backend=oracle_backend).decode()
+    assert (got.getWidth(), got.getHeight()) == (3840, 2160)
+    for c, (a, b) in enumerate(zip(got.buffer, exp.buffer)):
+        assert_bits_equal(a, b, "%s channel %d" % (name, c))
