@@ -74,6 +74,7 @@ struct jxl_ctx {
         group_tmp, bad_flag;
     int32_t woffs[51]{};
     std::vector<int32_t> h_hf_mul, h_sharp, h_xfy, h_bfy;
+    std::vector<float> h_kx, h_kb;
     std::vector<uint8_t> h_sel;
     std::vector<float> h_lf[3];
     std::vector<std::vector<DevBlock>> lfg_blocks;  // per LF group, reference order, frame coordinates
@@ -254,8 +255,20 @@ jxl_status finalize_tables(jxl_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(c->items.p, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->hf_mul.p, c->h_hf_mul.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->sharp.p, c->h_sharp.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->xfy.p, c->h_xfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->bfy.p, c->h_bfy.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
+    // chroma-from-luma factor per 64x64 tile, HFCoefficients.java:177-181: base + factor / colorFactor in float (one IEEE
+    // division and one addition, the same two operations the per-sample device code used to perform)
+    c->h_kx.resize(nt);
+    c->h_kb.resize(nt);
+    {
+        const volatile float cf = (float)c->p.color_factor;
+        for (size_t i = 0; i < nt; i++) {
+            const volatile float qx = (float)c->h_xfy[i] / cf, qb = (float)c->h_bfy[i] / cf;
+            c->h_kx[i] = c->p.base_corr_x + qx;
+            c->h_kb[i] = c->p.base_corr_b + qb;
+        }
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->xfy.p, c->h_kx.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->bfy.p, c->h_kb.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
     for (int ch = 0; ch < 3; ch++)
         HIP_TRY(c, hipMemcpyAsync(c->lf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
     // row f1: LF groups handed over as integers are dequantised + smoothed on the device, over the uploaded planes
@@ -293,8 +306,8 @@ void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
     }
     f.hf_mul = c->hf_mul.as<int32_t>();
     f.sharpness = c->sharp.as<int32_t>();
-    f.x_from_y = c->xfy.as<int32_t>();
-    f.b_from_y = c->bfy.as<int32_t>();
+    f.kx_tab = c->xfy.as<float>();
+    f.kb_tab = c->bfy.as<float>();
     f.weights = c->weights.as<float>();
     f.weights_t = c->weights_t.as<float>();
     memcpy(f.woffs, c->woffs, sizeof f.woffs);

@@ -39,8 +39,8 @@ struct DevFrame {
     const float* llf[3];    // [bh][bw]: lf with the LLF coefficients of blocks larger than 8x8 (k_llf)
     const int32_t* hf_mul;  // [bh][bw]
     const int32_t* sharpness;
-    const int32_t* x_from_y;  // [th][tw]
-    const int32_t* b_from_y;
+    const float* kx_tab;  // [th][tw]: baseCorrelationX + xFromY / colorFactor per 64x64 tile (HFCoefficients.java:177-181),
+    const float* kb_tab;  //           computed once per frame on the host (same IEEE float division and addition)
     const float* weights;     // flat, reciprocal
     const float* weights_t;   // same offsets, every matrix transposed (for flip() blocks: coalesced reads)
     int32_t woffs[51];

@@ -45,6 +45,9 @@ __device__ __forceinline__ constexpr float lutc(int n, int k) {
 }
 
 // MathHelper.inverseDCTHorizontal (MathHelper.java:68-78) on register arrays with compile-time strides
+// The float32 table is exactly mirror-(anti)symmetric, lut[n-1][N-1-k] == (-1)^n * lut[n-1][k] bit for bit (checked for
+// every N = 2..256 in tests/test_oracle_kats.py), and x * (-c) == -(x * c), a + (-p) == a - p exactly in IEEE arithmetic:
+// each product is formed once and added to output k and added / subtracted to output N-1-k. Same bits, half the multiplies.
 template <int N, int SS, int DS>
 __device__ __forceinline__ void idct1d_reg(const float* s, float* d) {
     const float s0 = s[0];
@@ -54,9 +57,43 @@ __device__ __forceinline__ void idct1d_reg(const float* s, float* d) {
     for (int n = 1; n < N; n++) {
         const float s2 = s[n * SS];
 #pragma unroll
-        for (int k = 0; k < N; k++) d[k * DS] = d[k * DS] + s2 * lutc<N>(n - 1, k);
+        for (int k = 0; k < N / 2; k++) {
+            const float p = s2 * lutc<N>(n - 1, k);
+            d[k * DS] = d[k * DS] + p;
+            d[(N - 1 - k) * DS] = (n & 1) ? d[(N - 1 - k) * DS] - p : d[(N - 1 - k) * DS] + p;
+        }
     }
 }
+
+// all L outputs of one 1-D IDCT held by a lane, as packed pairs: lo[j] = outputs (2j, 2j+1), hi[j] = outputs
+// (L-1-2j, L-2-2j) -- the mirror images of lo[j], so the same packed product updates both (see idct1d_reg)
+template <int L>
+struct MirrorAcc {
+    v2f lo[L / 4], hi[L / 4];
+    __device__ __forceinline__ void init(float s0) {
+#pragma unroll
+        for (int j = 0; j < L / 4; j++) lo[j] = hi[j] = v2f{s0, s0};
+    }
+    // lut_lo: the first L/2 entries of table row n-1 (or the lane's slice of them)
+    template <bool ODD>
+    __device__ __forceinline__ void step(float s, const float* lut_lo) {
+        const v2f s2 = {s, s};
+        const v2f* lr = reinterpret_cast<const v2f*>(lut_lo);
+#pragma unroll
+        for (int j = 0; j < L / 4; j++) {
+            const v2f p = s2 * lr[j];
+            lo[j] = lo[j] + p;
+            hi[j] = ODD ? hi[j] - p : hi[j] + p;
+        }
+    }
+    // output i of the L this lane holds: i < L/2 counts up from the lane's first low output, i >= L/2 continues through
+    // the mirrored ones so that get(L-1-i) is the mirror of get(i)
+    __device__ __forceinline__ float get(int i) const {
+        if (i < L / 2) return (i & 1) ? lo[i / 2].y : lo[i / 2].x;
+        const int m = L - 1 - i;
+        return (m & 1) ? hi[m / 2].y : hi[m / 2].x;
+    }
+};
 
 // MathHelper.inverseDCT2D (MathHelper.java:96-122). src is H x W (row stride SS).
 // TRANSPOSED=false: dst is H x W; true: dst is W rows x H columns. Row stride of dst = DS.
@@ -252,8 +289,8 @@ __device__ __forceinline__ void cfl_factors(const DevFrame& f, int ty, int tx, b
         kX = 0.0f;
         kB = 0.0f;
     } else {
-        kX = f.base_corr_x + (float)f.x_from_y[ty * f.tw + tx] / f.color_factor_f;
-        kB = f.base_corr_b + (float)f.b_from_y[ty * f.tw + tx] / f.color_factor_f;
+        kX = f.kx_tab[ty * f.tw + tx];
+        kB = f.kb_tab[ty * f.tw + tx];
     }
 }
 
@@ -552,7 +589,7 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
             const float* lfp = f.lf[c] + (int64_t)b.cy * f.bw + b.cx;
             const float* lut = f.lut + lut_off(ceil_log2_dev(H));
             float kcfl = 0.0f;
-            v2f acc[H / 2];
+            MirrorAcc<H> acc;
             // rows in chunks of RC: all global loads of a chunk are issued before its arithmetic, so RC (x2-4)
             // loads per lane are in flight instead of one dependent load per row
             constexpr int RC = 8;
@@ -589,25 +626,16 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
                             co = co + kcfl * dy;  // chromaFromLuma (:186-188)
                         }
                     }
-                    // packed f32: two outputs per instruction (v_pk_mul_f32 + v_pk_add_f32; still one rounding per
-                    // multiply and per add, same order per output)
-                    const v2f co2 = {co, co};
-                    if (n == 0) {
-#pragma unroll
-                        for (int k = 0; k < H / 2; k++) acc[k] = co2;
-                    } else {
-                        const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * H);
-#pragma unroll
-                        for (int k = 0; k < H / 2; k++) acc[k] = acc[k] + co2 * lr[k];
-                    }
+                    // packed f32 (v_pk_mul_f32 + v_pk_add_f32: one rounding per multiply and per add, same order per
+                    // output); n0 is a multiple of RC = 8, so the parity of n is the parity of r
+                    if (n == 0) acc.init(co);
+                    else if (r & 1) acc.template step<true>(co, lut + (n - 1) * H);
+                    else acc.template step<false>(co, lut + (n - 1) * H);
                 }
             }
             float* dcol = lds + bi * IMG + x;
 #pragma unroll
-            for (int k = 0; k < H / 2; k++) {
-                dcol[(2 * k) * LD] = acc[k].x;
-                dcol[(2 * k + 1) * LD] = acc[k].y;
-            }
+            for (int k = 0; k < H; k++) dcol[k * LD] = acc.get(k);
         }
     }
     __syncthreads();  // orders the wave's LDS image for the row pass (all 4 waves run the same sequence)
@@ -618,21 +646,16 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
             const DevBlock b = blocks[wfirst + bi];
             const float* row = lds + bi * IMG + y * LD;
             const float* lut = f.lut + lut_off(ceil_log2_dev(W));
-            v2f acc[W / 2];
-            const float s0 = row[0];
-#pragma unroll
-            for (int k = 0; k < W / 2; k++) acc[k] = v2f{s0, s0};
-#pragma unroll 8
-            for (int n = 1; n < W; n++) {
-                const float s2 = row[n];
-                const v2f s22 = {s2, s2};
-                const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * W);
-#pragma unroll
-                for (int k = 0; k < W / 2; k++) acc[k] = acc[k] + s22 * lr[k];
+            MirrorAcc<W> acc;
+            acc.init(row[0]);
+#pragma unroll 4
+            for (int n = 1; n < W; n += 2) {  // (odd, even) pairs; W is even, so the last odd n stands alone
+                acc.template step<true>(row[n], lut + (n - 1) * W);
+                if (n + 1 < W) acc.template step<false>(row[n + 1], lut + n * W);
             }
             float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8;
 #pragma unroll
-            for (int k = 0; k < W / 2; k += 2) *reinterpret_cast<float4*>(o + 2 * k) = make_float4(acc[k].x, acc[k].y, acc[k + 1].x, acc[k + 1].y);
+            for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(o + k) = make_float4(acc.get(k), acc.get(k + 1), acc.get(k + 2), acc.get(k + 3));
         }
     }
 }
@@ -701,6 +724,19 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         const int x = tid % W, r0 = tid / W;
         int qcv[NS], qyv[NS];
         float wcv[NS], wyv[NS];
+        // per-block scale factors once per lane (scaleFactor[c] / hfMul, HFCoefficients.java:299): NBLK divisions instead
+        // of one per sample
+        float sfc_b[NBLK], sfy_b[NBLK];
+#pragma unroll
+        for (int bi = 0; bi < NBLK; bi++) {
+            sfc_b[bi] = sfy_b[bi] = 0.0f;
+            if (bi < nb) {
+                const DevBlock b = blocks[it.first + bi];
+                const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+                sfc_b[bi] = f.scale_factor[c] / hfm;
+                sfy_b[bi] = f.scale_factor[1] / hfm;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             const int bi = j / BSTEP, n = (j % BSTEP) * RSTEP + r0;
@@ -723,17 +759,16 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             if (bi < nb) {
                 const DevBlock b = blocks[it.first + bi];
                 const int py0 = b.cy * 8, px0 = b.cx * 8;
-                const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
                 float co;
                 if (n < DSH && x < DSW) {
                     co = llf_coeff<DSH, DSW>(f, f.lf[c] + (int64_t)b.cy * f.bw + b.cx, n, x);
                 } else {
-                    co = dequant1_tab(qcv[j], f.quant_bias[c], qbn, f.scale_factor[c] / hfm, wcv[j], qtab);
+                    co = dequant1_tab(qcv[j], f.quant_bias[c], qbn, sfc_b[bi], wcv[j], qtab);
                     if (c != 1) {
                         const int ty = (py0 + n) >> 6, tx = (px0 + x) >> 6;
                         float kX, kB;
                         cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - (py0 >> 6)) * 5 + (tx - (px0 >> 6)))) & 1u, kX, kB);
-                        const float dy = dequant1_tab(qyv[j], f.quant_bias[1], qbn, f.scale_factor[1] / hfm, wyv[j], qtab);
+                        const float dy = dequant1_tab(qyv[j], f.quant_bias[1], qbn, sfy_b[bi], wyv[j], qtab);
                         co = co + (c == 0 ? kX : kB) * dy;
                     }
                 }
@@ -748,25 +783,22 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         const int col = tid % (NBLK * W), kc = __builtin_amdgcn_readfirstlane(tid / (NBLK * W));
         const int bi = col / W, x = col % W;
         if (bi < nb) {
+            // chunk kc = outputs [kc*KC/2, (kc+1)*KC/2) and their mirror images [H-(kc+1)*KC/2, H-kc*KC/2): one product
+            // serves output k and output H-1-k (see idct1d_reg), so a lane keeps both halves of its KC outputs
             const float* src = img0 + bi * IMG + x;
-            const float* lut = f.lut + lut_off(ceil_log2_dev(H)) + kc * KC;
-            v2f acc[KC / 2];
-            const float s0 = src[0];
-#pragma unroll
-            for (int k = 0; k < KC / 2; k++) acc[k] = v2f{s0, s0};
-#pragma unroll 4
-            for (int n = 1; n < H; n++) {
-                const float s2 = src[n * LD];
-                const v2f s22 = {s2, s2};
-                const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * H);
-#pragma unroll
-                for (int k = 0; k < KC / 2; k++) acc[k] = acc[k] + s22 * lr[k];
+            const float* lut = f.lut + lut_off(ceil_log2_dev(H)) + kc * (KC / 2);
+            MirrorAcc<KC> acc;
+            acc.init(src[0]);
+#pragma unroll 2
+            for (int n = 1; n < H; n += 2) {
+                acc.template step<true>(src[n * LD], lut + (n - 1) * H);
+                if (n + 1 < H) acc.template step<false>(src[(n + 1) * LD], lut + n * H);
             }
-            float* d = img1 + bi * IMG + (kc * KC) * LD + x;
+            float* d = img1 + bi * IMG + x;
 #pragma unroll
-            for (int k = 0; k < KC / 2; k++) {
-                d[(2 * k) * LD] = acc[k].x;
-                d[(2 * k + 1) * LD] = acc[k].y;
+            for (int i = 0; i < KC / 2; i++) {
+                d[(kc * (KC / 2) + i) * LD] = acc.get(i);
+                d[(H - 1 - kc * (KC / 2) - i) * LD] = acc.get(KC - 1 - i);
             }
         }
     }
@@ -779,22 +811,24 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         if (bi < nb) {
             const DevBlock b = blocks[it.first + bi];
             const float* row = img1 + bi * IMG + y * LD;
-            const float* lut = f.lut + lut_off(ceil_log2_dev(W)) + kc * KC;
-            v2f acc[KC / 2];
-            const float s0 = row[0];
-#pragma unroll
-            for (int k = 0; k < KC / 2; k++) acc[k] = v2f{s0, s0};
-#pragma unroll 4
-            for (int n = 1; n < W; n++) {
-                const float s2 = row[n];
-                const v2f s22 = {s2, s2};
-                const v2f* lr = reinterpret_cast<const v2f*>(lut + (n - 1) * W);
-#pragma unroll
-                for (int k = 0; k < KC / 2; k++) acc[k] = acc[k] + s22 * lr[k];
+            const float* lut = f.lut + lut_off(ceil_log2_dev(W)) + kc * (KC / 2);
+            MirrorAcc<KC> acc;
+            acc.init(row[0]);
+#pragma unroll 2
+            for (int n = 1; n < W; n += 2) {
+                acc.template step<true>(row[n], lut + (n - 1) * W);
+                if (n + 1 < W) acc.template step<false>(row[n + 1], lut + n * W);
             }
-            float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8 + kc * KC;
+            // two runs of KC/2 consecutive outputs: the low one ascending, the mirrored one ending at W-1-kc*KC/2
+            float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8;
+            float* olo = o + kc * (KC / 2);
+            float* ohi = o + W - (kc + 1) * (KC / 2);
 #pragma unroll
-            for (int k = 0; k < KC / 2; k += 2) *reinterpret_cast<float4*>(o + 2 * k) = make_float4(acc[k].x, acc[k].y, acc[k + 1].x, acc[k + 1].y);
+            for (int k = 0; k < KC / 2; k += 4) {
+                *reinterpret_cast<float4*>(olo + k) = make_float4(acc.get(k), acc.get(k + 1), acc.get(k + 2), acc.get(k + 3));
+                // ohi[t] is output W-(kc+1)*KC/2+t = mirror of low output i = KC/2-1-t, i.e. get(KC-1-i) = get(KC/2+t)
+                *reinterpret_cast<float4*>(ohi + k) = make_float4(acc.get(KC / 2 + k), acc.get(KC / 2 + k + 1), acc.get(KC / 2 + k + 2), acc.get(KC / 2 + k + 3));
+            }
         }
     }
 }

@@ -351,3 +351,16 @@ def test_rct_inverse_of_forward(orc, rct_type):
     enc = np.stack([a, b, c]).astype(np.int32)
     out = orc.rct(enc, rct_type)
     assert np.array_equal(out, rgb)
+
+
+def test_cosine_lut_is_exactly_mirror_symmetric(orc):
+    """lut[n-1][N-1-k] == (-1)^n * lut[n-1][k] bit for bit, for every N: the device IDCT kernels form each product once and
+    add / subtract it into the mirrored output (k_idct.hip, idct1d_reg) -- exact only because of this property"""
+    for l in range(1, 9):
+        lut = orc.cosine_lut(l)
+        s = 1 << l
+        for n in range(1, s):
+            row = lut[n - 1]
+            mirrored = row[::-1] * (np.float32(-1.0) if n % 2 else np.float32(1.0))
+            assert np.array_equal(row.view(np.uint32), mirrored.view(np.uint32)), (s, n)
+        assert not (lut == 0).any()  # no signed-zero ambiguity

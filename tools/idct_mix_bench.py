@@ -1,6 +1,6 @@
 """IDCT-stage time (HIP events) for single-type 4K frames: where does k_idct_main spend its time?"""
 import sys, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from jxlatte_amd import _lib, abi, host, synth
 ctx = _lib.Context(0)

@@ -1,6 +1,6 @@
 """CPU-side enqueue cost of jxl_vardct_run vs GPU time per 4K frame"""
 import sys, time, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from jxlatte_amd import _lib, abi, host, synth
 ctx = _lib.Context(0)
 fr = synth.make_vardct_frame(3840, 2160, seed=1000)
