@@ -103,6 +103,15 @@ typedef struct jxl_vardct_params {
 
     int32_t transfer;   /* JXL_TRANSFER_* */
     int32_t out_format; /* JXL_OUT_* */
+
+    /* row a16, JPEG-recompressed frames: FrameHeader.jpegUpsamplingY/X[c] AFTER the header's normalisation
+     * (FrameHeader.java:190-195: max - own), i.e. the shift by which channel c (X/Cb, Y, B/Cr buffer order) is smaller
+     * than the padded frame. All zero for ordinary frames. With a non-zero shift: put_group planes, lf[] planes and the
+     * coefficient positions of channel c are in its own subsampled geometry (PassGroup.java:213-226), chroma-from-luma
+     * is skipped (HFCoefficients.java:149-151), and Frame.invertSubsampling (Frame.java:681-723) runs right after the
+     * inverse transforms, before Gab / EPF. */
+    int32_t jpeg_upsampling_y[3];
+    int32_t jpeg_upsampling_x[3];
 } jxl_vardct_params;
 
 /* One LF group's side information, in the reference's own per-LF-group shape

@@ -84,6 +84,7 @@ class VarDCTParams(C.Structure):
         ("epf_pass2_sigma_scale", C.c_float), ("epf_border_sad_mul", C.c_float),
         ("xyb", C.c_int32), ("opsin_matrix", f9), ("opsin_bias", f3), ("cbrt_opsin_bias", f3),
         ("intensity_target", C.c_float), ("transfer", C.c_int32), ("out_format", C.c_int32),
+        ("jpeg_upsampling_y", C.c_int32 * 3), ("jpeg_upsampling_x", C.c_int32 * 3),
     ]
 
 
@@ -108,14 +109,17 @@ class LFQuantDesc(C.Structure):
 
 
 def make_lfquant_desc(lf_quant, scaled_dequant, extra_precision=0, x_factor_lf=128, b_factor_lf=128, adaptive_smoothing=True,
-                      lfg_y=0, lfg_x=0):
-    """lf_quant: int32 array [3][H][W] in X,Y,B order (kept alive by the caller)."""
-    assert lf_quant.dtype == np.int32 and lf_quant.ndim == 3 and lf_quant.flags["C_CONTIGUOUS"]
+                      lfg_y=0, lfg_x=0, cells=None):
+    """lf_quant: int32 array [3][H][W] in X,Y,B order, or (chroma-subsampled frames) a list of three contiguous int32 planes
+    of different sizes together with cells=(cells_h, cells_w) of the LF group. Kept alive by the caller."""
+    planes = [lf_quant[c] for c in range(3)]
+    for a in planes:
+        assert a.dtype == np.int32 and a.ndim == 2 and a.flags["C_CONTIGUOUS"]
     d = LFQuantDesc()
     d.lfg_y, d.lfg_x = lfg_y, lfg_x
-    d.cells_h, d.cells_w = lf_quant.shape[1:]
+    d.cells_h, d.cells_w = cells if cells is not None else max(a.shape for a in planes)
     for c in range(3):
-        d.lf_quant[c] = iptr(lf_quant[c])
+        d.lf_quant[c] = iptr(planes[c])
         d.scaled_dequant[c] = scaled_dequant[c]
     d.extra_precision, d.x_factor_lf, d.b_factor_lf = extra_precision, x_factor_lf, b_factor_lf
     d.adaptive_smoothing = 1 if adaptive_smoothing else 0

@@ -83,9 +83,13 @@ struct jxl_ctx {
     std::vector<LfJob> lf_jobs;  // integer LF images to dequantise + smooth on the device (row f1)
     DevBuf lfq_tmp[3];
     // binned work
-    struct TypeLaunch { int type, items_off, n_items; };
+    struct TypeLaunch { int type, items_off, n_items, channel; };  // channel >= 0: chroma-subsampled frame, one channel per launch
+    bool sub = false;      // any jpeg_upsampling shift non-zero
+    int sy[3] = {0, 0, 0}, sx[3] = {0, 0, 0};
+    DevBuf hfm_sub[3];     // hfMultiplier resampled onto each channel's cell grid
+    struct SpecialLaunch { int items_off, n_items, channel; };
+    std::vector<SpecialLaunch> special_launches;
     std::vector<TypeLaunch> type_launches;
-    int special_off = 0, n_special_items = 0;
     int large_first = 0, large_count = 0;
     int llf_first = 0, llf_count = 0;  // blocks larger than 8x8 (contiguous in h_blocks)
     std::vector<DevBlock> h_blocks;
@@ -207,43 +211,75 @@ jxl_status finalize_tables(jxl_ctx* c) {
         }
     }
     // layout: [8x8-footprint types..., medium types..., large types...]; expensive items first so that the
-    // tail of the single launch is made of cheap workgroups
+    // tail of the single launch is made of cheap workgroups. Chroma-subsampled frames (c->sub) get one such layout per
+    // channel: only the blocks aligned to the channel's grid, in the channel's own cell coordinates
+    // (HFCoefficients.java:292-297, PassGroup.java:215-221), and one launch set per channel.
     c->h_blocks.clear();
     std::vector<WorkItem> items;
-    c->llf_first = -1;
-    std::vector<uint32_t> first_of(JXL_NUM_TRANSFORM_TYPES, 0);
-    for (int pass = 0; pass < 2; pass++)
-        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
-            if (is_large(t) || sm[t].empty() || is_small(t) != (pass == 0)) continue;
-            if (pass == 1 && c->llf_first < 0) c->llf_first = (int)c->h_blocks.size();
-            first_of[t] = (uint32_t)c->h_blocks.size();
-            c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
-        }
-    static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     c->type_launches.clear();
-    for (int t : kOrder) {
-        if (sm[t].empty()) continue;
-        jxl_ctx::TypeLaunch tl{t, (int)items.size(), 0};
-        const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
-        for (uint32_t o = 0; o < sm[t].size(); o += nb)
-            for (uint32_t ch = 0; ch < 3; ch++)
-                items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(nb, sm[t].size() - o)});
-        tl.n_items = (int)items.size() - tl.items_off;
-        c->type_launches.push_back(tl);
-    }
-    c->special_off = (int)items.size();
+    c->special_launches.clear();
+    static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
-    for (int t : kSpecial)
-        for (uint32_t o = 0; o < sm[t].size(); o += 64)
-            for (uint32_t ch = 0; ch < 3; ch++)
-                items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(64, sm[t].size() - o)});
-    c->n_special_items = (int)items.size() - c->special_off;
+    auto lay_out = [&](const std::vector<DevBlock>* lists, int channel) {
+        std::vector<uint32_t> first_of(JXL_NUM_TRANSFORM_TYPES, 0);
+        for (int pass = 0; pass < 2; pass++)
+            for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
+                if (is_large(t) || lists[t].empty() || is_small(t) != (pass == 0)) continue;
+                first_of[t] = (uint32_t)c->h_blocks.size();
+                c->h_blocks.insert(c->h_blocks.end(), lists[t].begin(), lists[t].end());
+            }
+        const uint32_t ch0 = channel < 0 ? 0 : (uint32_t)channel, ch1 = channel < 0 ? 3 : (uint32_t)channel + 1;
+        for (int t : kOrder) {
+            if (lists[t].empty()) continue;
+            jxl_ctx::TypeLaunch tl{t, (int)items.size(), 0, channel};
+            const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
+            for (uint32_t o = 0; o < lists[t].size(); o += nb)
+                for (uint32_t ch = ch0; ch < ch1; ch++)
+                    items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(nb, lists[t].size() - o)});
+            tl.n_items = (int)items.size() - tl.items_off;
+            c->type_launches.push_back(tl);
+        }
+        jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel};
+        for (int t : kSpecial)
+            for (uint32_t o = 0; o < lists[t].size(); o += 64)
+                for (uint32_t ch = ch0; ch < ch1; ch++)
+                    items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(64, lists[t].size() - o)});
+        sl.n_items = (int)items.size() - sl.items_off;
+        if (sl.n_items > 0) c->special_launches.push_back(sl);
+    };
+    std::vector<int32_t> h_hfm_sub[3];
+    if (!c->sub) {
+        lay_out(sm, -1);
+    } else {
+        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+            if (is_large(t) && !sm[t].empty())
+                return fail(c, JXL_ERR_UNSUPPORTED, "128/256-edge varblocks in a chroma-subsampled frame");
+        for (int ch = 0; ch < 3; ch++) {
+            const int sy = c->sy[ch], sx = c->sx[ch], bwc = c->bw >> sx, bhc = c->bh >> sy;
+            std::vector<DevBlock> sub_lists[JXL_NUM_TRANSFORM_TYPES];
+            h_hfm_sub[ch].assign((size_t)bwc * bhc, 1);
+            for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+                for (const DevBlock& b : sm[t]) {
+                    const int cy2 = b.cy >> sy, cx2 = b.cx >> sx;
+                    if ((cy2 << sy) != b.cy || (cx2 << sx) != b.cx) continue;  // subsampled away
+                    if (cy2 * 8 + JXL_TT[t].ph > (c->H >> sy) || cx2 * 8 + JXL_TT[t].pw > (c->W >> sx))
+                        return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock (%d,%d) leaves the subsampled channel %d", b.cy, b.cx, ch);
+                    sub_lists[t].push_back(DevBlock{(uint16_t)cy2, (uint16_t)cx2, b.type, 0u});
+                    h_hfm_sub[ch][(size_t)cy2 * bwc + cx2] = c->h_hf_mul[(size_t)b.cy * c->bw + b.cx];
+                }
+            lay_out(sub_lists, ch);
+        }
+    }
     c->large_first = (int)c->h_blocks.size();
     for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
         if (is_large(t)) c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
     c->large_count = (int)c->h_blocks.size() - c->large_first;
     c->llf_first = c->large_first;  // only the 128/256-edge blocks take their LLF from the llf planes (k_llf)
     c->llf_count = c->large_count;
+    for (int ch = 0; ch < 3 && c->sub; ch++) {
+        if (!c->hfm_sub[ch].ensure(4 * std::max<size_t>(1, h_hfm_sub[ch].size()))) return fail(c, JXL_ERR_OOM, "device allocation failed");
+        HIP_TRY(c, hipMemcpyAsync(c->hfm_sub[ch].p, h_hfm_sub[ch].data(), 4 * h_hfm_sub[ch].size(), hipMemcpyHostToDevice, c->stream));
+    }
 
     if (!c->blocks.ensure(sizeof(DevBlock) * std::max<size_t>(1, c->h_blocks.size())) ||
         !c->items.ensure(sizeof(WorkItem) * std::max<size_t>(1, items.size())))
@@ -274,6 +310,19 @@ jxl_status finalize_tables(jxl_ctx* c) {
     // row f1: LF groups handed over as integers are dequantised + smoothed on the device, over the uploaded planes
     for (const auto& job : c->lf_jobs) {
         const jxl_lfquant_desc& d = job.d;
+        if (c->sub) {  // per channel, own geometry, no CfL, no smoothing (LFCoefficients.java:66-75 only)
+            for (int ch = 0; ch < 3; ch++) {
+                const int h2 = d.cells_h >> c->sy[ch], w2 = d.cells_w >> c->sx[ch], bw2 = c->bw >> c->sx[ch];
+                const size_t n2 = (size_t)h2 * w2;
+                if (!c->lfq_tmp[ch].ensure(4 * std::max<size_t>(1, n2))) return fail(c, JXL_ERR_OOM, "device allocation failed (LF image)");
+                HIP_TRY(c, hipMemcpyAsync(c->lfq_tmp[ch].p, job.q[ch].data(), 4 * n2, hipMemcpyHostToDevice, c->stream));
+                launch_lf_dequant_plain(c->lfq_tmp[ch].as<int32_t>(), c->lf[ch].as<float>(), h2, w2,
+                                        (int64_t)((d.lfg_y * 256) >> c->sy[ch]) * bw2 + ((d.lfg_x * 256) >> c->sx[ch]), bw2,
+                                        d.scaled_dequant[ch], d.extra_precision, c->stream);
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            continue;
+        }
         const size_t n = (size_t)d.cells_h * d.cells_w;
         const int32_t* dq[3];
         for (int ch = 0; ch < 3; ch++) {
@@ -296,6 +345,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
 }
 
 void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
+    f.no_cfl = 0;
     f.width = c->W; f.height = c->H; f.bw = c->bw; f.bh = c->bh; f.tw = c->tw; f.th = c->th;
     for (int ch = 0; ch < 3; ch++) {
         f.coeff[ch] = c->coeff[ch].as<int32_t>();
@@ -460,6 +510,16 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     if (p->epf_iters < 0 || p->epf_iters > 3) return fail(c, JXL_ERR_INVALID_BITSTREAM, "epfIterations %d", p->epf_iters);
     if (p->out_format < 0 || p->out_format > JXL_OUT_RGB16 || p->transfer < 0 || p->transfer > 2)
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output stage selector");
+    c->sub = false;
+    for (int i = 0; i < 3; i++) {
+        c->sy[i] = p->jpeg_upsampling_y[i];
+        c->sx[i] = p->jpeg_upsampling_x[i];
+        if (c->sy[i] < 0 || c->sy[i] > 1 || c->sx[i] < 0 || c->sx[i] > 1)
+            return fail(c, JXL_ERR_INVALID_ARGUMENT, "jpeg upsampling shift of channel %d out of range", i);
+        c->sub = c->sub || c->sy[i] || c->sx[i];
+    }
+    if (c->sub && ((p->width & 15) || (p->height & 15)))
+        return fail(c, JXL_ERR_INVALID_ARGUMENT, "a chroma-subsampled frame is padded to multiples of 16 (Frame.getPaddedFrameSize)");
     c->p = *p;
     c->W = p->width; c->H = p->height;
     c->bw = c->W / 8; c->bh = c->H / 8;
@@ -552,10 +612,19 @@ jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
             c->h_hf_mul[d] = g->hf_mul[s];
             c->h_sharp[d] = g->sharpness[s];
             c->h_sel[d] = g->dct_select[s];
-            for (int ch = 0; ch < 3; ch++)
-                if (g->lf[ch]) c->h_lf[ch][d] = g->lf[ch][s];
+            if (!c->sub)
+                for (int ch = 0; ch < 3; ch++)
+                    if (g->lf[ch]) c->h_lf[ch][d] = g->lf[ch][s];
         }
     }
+    if (c->sub)  // lf[ch] is (cells_h >> sy) x (cells_w >> sx), placed on the channel's own cell grid (LFCoefficients.java:38-44)
+        for (int ch = 0; ch < 3; ch++) {
+            if (!g->lf[ch]) continue;
+            const int h2 = eh >> c->sy[ch], w2 = ew >> c->sx[ch], bw2 = c->bw >> c->sx[ch];
+            for (int y = 0; y < h2; y++)
+                for (int x = 0; x < w2; x++)
+                    c->h_lf[ch][(size_t)((y0 >> c->sy[ch]) + y) * bw2 + (x0 >> c->sx[ch]) + x] = g->lf[ch][(size_t)y * w2 + x];
+        }
     for (int y = 0; y < gth; y++)
         for (int x = 0; x < gtw; x++) {
             const size_t d = (size_t)(g->lfg_y * 32 + y) * c->tw + g->lfg_x * 32 + x;
@@ -593,10 +662,12 @@ jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* c, const jxl_lfquant_desc* d)
     if (d->lfg_x < 0 || d->lfg_x >= lrs || d->lfg_y < 0 || d->lfg_y >= lcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group position out of range");
     const int eh = std::min(256, c->bh - d->lfg_y * 256), ew = std::min(256, c->bw - d->lfg_x * 256);
     if (d->cells_h != eh || d->cells_w != ew) return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group (%d,%d) must be %dx%d cells", d->lfg_y, d->lfg_x, eh, ew);
+    if (c->sub && d->adaptive_smoothing)
+        return fail(c, JXL_ERR_INVALID_BITSTREAM, "Adaptive Smoothing is incompatible with subsampling");  // LFCoefficients.java:36-37
     jxl_ctx::LfJob job;
     job.d = *d;
-    const size_t n = (size_t)eh * ew;
     for (int ch = 0; ch < 3; ch++) {
+        const size_t n = (size_t)(eh >> c->sy[ch]) * (ew >> c->sx[ch]);
         job.q[ch].assign(d->lf_quant[ch], d->lf_quant[ch] + n);
         job.d.lf_quant[ch] = nullptr;
     }
@@ -642,14 +713,16 @@ jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const i
     const int gy = group / grs, gx = group % grs;  // Frame.getGroupLocation (Frame.java:883)
     const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);  // getGroupSize (:905)
     for (int ch = 0; ch < 3; ch++) {
-        if (!q[ch] || stride[ch] < gw) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
-        int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)(gy * 256) * c->W + gx * 256;
+        // channel geometry (HFCoefficients.java:64-69, PassGroup.java:223-226): all shifts are zero for ordinary frames
+        const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
+        if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
+        int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)((gy * 256) >> c->sy[ch]) * Wc + ((gx * 256) >> c->sx[ch]);
         if (pass == 0) {
-            HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->W * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gw * 4, gh, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)Wc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
         } else {
-            HIP_TRY(c, hipMemcpy2DAsync(c->group_tmp.p, (size_t)gw * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gw * 4, gh, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_accumulate2d, dim3(ceil_div(gw, 64), ceil_div(gh, 4)), dim3(256), 0, c->stream, dst, (int64_t)c->W,
-                               c->group_tmp.as<int32_t>(), gw, gh);
+            HIP_TRY(c, hipMemcpy2DAsync(c->group_tmp.p, (size_t)gwc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_accumulate2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, dst, (int64_t)Wc,
+                               c->group_tmp.as<int32_t>(), gwc, ghc);
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller's buffer is pageable and may be reused
     }
@@ -686,8 +759,21 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
             launch_llf(f, blocks, c->llf_first, c->llf_count, L, s);
             launches++;
         }
+        // chroma-subsampled frames: the launch of channel ch sees that channel's geometry
+        auto frame_of = [&](int channel) {
+            DevFrame fc = f;
+            if (channel >= 0) {
+                fc.no_cfl = 1;
+                fc.width = c->W >> c->sx[channel];
+                fc.height = c->H >> c->sy[channel];
+                fc.bw = c->bw >> c->sx[channel];
+                fc.bh = c->bh >> c->sy[channel];
+                fc.hf_mul = c->hfm_sub[channel].as<int32_t>();
+            }
+            return fc;
+        };
         // fork: every type kernel writes a disjoint set of varblocks
-        const int n_k = (int)c->type_launches.size() + (c->n_special_items > 0 ? 1 : 0);
+        const int n_k = (int)c->type_launches.size() + (int)c->special_launches.size();
         const bool fork = n_k > 1 && c->n_aux > 0;
         int used = 0;
         if (fork) {
@@ -698,11 +784,11 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         int k = 0;
         auto pick = [&]() { const int i = k++; return (!fork || i % (used + 1) == 0) ? s : c->aux[i % (used + 1) - 1]; };
         for (const auto& tl : c->type_launches) {
-            launch_idct_type(f, blocks, items + tl.items_off, tl.n_items, tl.type, A, pick());
+            launch_idct_type(frame_of(tl.channel), blocks, items + tl.items_off, tl.n_items, tl.type, A, pick());
             launches++;
         }
-        if (c->n_special_items > 0) {
-            launch_idct_special(f, blocks, items + c->special_off, c->n_special_items, A, pick());
+        for (const auto& sl : c->special_launches) {
+            launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, pick());
             launches++;
         }
         if (fork)
@@ -712,9 +798,28 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
             }
         if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
     }
+    // Frame.invertSubsampling (Frame.java:457, 681-723): horizontal doublings, then vertical ones, per channel
+    float* curp[3] = {A[0], A[1], A[2]};
+    float* othp[3] = {B[0], B[1], B[2]};
+    if (c->sub && (p.stages & JXL_STAGE_IDCT))
+        for (int ch = 0; ch < 3; ch++) {
+            int h2 = c->H >> c->sy[ch], w2 = c->W >> c->sx[ch];
+            for (int i = 0; i < c->sx[ch]; i++) {
+                launch_chroma_upsample_h(curp[ch], h2, w2, othp[ch], s);
+                w2 *= 2;
+                std::swap(curp[ch], othp[ch]);
+                launches++;
+            }
+            for (int i = 0; i < c->sy[ch]; i++) {
+                launch_chroma_upsample_v(curp[ch], h2, w2, othp[ch], s);
+                h2 *= 2;
+                std::swap(curp[ch], othp[ch]);
+                launches++;
+            }
+        }
     if (c->timing) (void)hipEventRecord(evs[1], s);
-    float** cur = A;
-    float** oth = B;
+    float** cur = curp;
+    float** oth = othp;
     const bool do_gab = (p.stages & JXL_STAGE_GAB) && p.gab;
     const bool do_epf = (p.stages & JXL_STAGE_EPF) && p.epf_iters > 0;
     const bool do_xyb = (p.stages & JXL_STAGE_XYB) && p.xyb;

@@ -31,6 +31,8 @@ struct WorkItem {
 
 // Device-resident view of one VarDCT frame (all pointers are device pointers).
 struct DevFrame {
+    int32_t no_cfl;         // chroma-subsampled frame: chroma-from-luma is skipped (HFCoefficients.java:149-151) and the
+                            // geometry below is the one of the channel the launch handles
     int32_t width, height;  // padded px
     int32_t bw, bh;         // cells
     int32_t tw, th;         // 64x64 tiles
@@ -134,6 +136,9 @@ void launch_rct(int32_t* v0, int32_t* v1, int32_t* v2, int64_t n, int type, hipS
 void launch_modular_to_float(const int32_t* a, const int32_t* b, int64_t n, float scale, float* out, hipStream_t s);
 
 // LF stage (row f1): q/out device pointers; out written at out_off + y*out_stride + x
+// one channel of a chroma-subsampled frame: out = q * (scaledDequant / (1 << extraPrecision)), no CfL, no smoothing
+void launch_lf_dequant_plain(const int32_t* q, float* out, int H, int W, int64_t out_off, int out_stride, float scaled_dequant,
+                             int extra_precision, hipStream_t s);
 void launch_lf_dequant(const int32_t* const q[3], float* const out[3], int H, int W, int64_t out_off, int out_stride,
                        const float scaled_dequant[3], int extra_precision, float base_corr_x, float base_corr_b,
                        int color_factor, int x_factor_lf, int b_factor_lf, int smooth, hipStream_t s);

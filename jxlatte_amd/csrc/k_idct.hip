@@ -315,7 +315,7 @@ __device__ __forceinline__ void small_row(const DevFrame& f, int c, int y, int64
     const float qb = f.quant_bias[c];
 #pragma unroll
     for (int x = 0; x < 8; x++) co[x] = dequant1(q[x], qb, qbn, sfc, w[FLIP ? x * 8 + y : y * 8 + x]);
-    if (c != 1) {
+    if (c != 1 && !f.no_cfl) {
         int qy[8];
         load8(1, qy);
         const float* wy = f.weights + f.woffs[PI * 3 + 1];
@@ -602,7 +602,7 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
                 for (int r = 0; r < RC; r++) {
                     qcv[r] = qc_plane[off0 + (int64_t)r * FW];
                     wcv[r] = wc[(n0 + r) * W + x];  // (FLIP ? transposed table : table)[n][x]
-                    if (c != 1) {
+                    if (c != 1 && !f.no_cfl) {
                         qyv[r] = qy_plane[off0 + (int64_t)r * FW];
                         wyv[r] = wy[(n0 + r) * W + x];
                     }
@@ -611,7 +611,7 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
                 for (int r = 0; r < RC; r++) {
                     const int n = n0 + r;
                     float co;
-                    if (c != 1 && (n == 0 || ((py0 + n) & 63) == 0)) {  // entering a new CfL tile row
+                    if (c != 1 && !f.no_cfl && (n == 0 || ((py0 + n) & 63) == 0)) {  // entering a new CfL tile row
                         const int ty = (py0 + n) >> 6;
                         float kX, kB;
                         cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - ty0) * 5 + (tx - tx0))) & 1u, kX, kB);
@@ -621,7 +621,7 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
                         co = llf_coeff<DSH, DSW>(f, lfp, n, x);  // finalizeLLF (:194-229)
                     } else {
                         co = dequant1_tab(qcv[r], qbc, qbn, sfc, wcv[r], qtab);
-                        if (c != 1) {
+                        if (c != 1 && !f.no_cfl) {
                             const float dy = dequant1_tab(qyv[r], qby, qbn, sfy, wyv[r], qtab);
                             co = co + kcfl * dy;  // chromaFromLuma (:186-188)
                         }
@@ -747,7 +747,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
                 const int64_t off = (int64_t)(b.cy * 8 + n) * FW + b.cx * 8 + x;
                 qcv[j] = f.coeff[c][off];
                 wcv[j] = wc[n * W + x];
-                if (c != 1) {
+                if (c != 1 && !f.no_cfl) {
                     qyv[j] = f.coeff[1][off];
                     wyv[j] = wy[n * W + x];
                 }
@@ -764,7 +764,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
                     co = llf_coeff<DSH, DSW>(f, f.lf[c] + (int64_t)b.cy * f.bw + b.cx, n, x);
                 } else {
                     co = dequant1_tab(qcv[j], f.quant_bias[c], qbn, sfc_b[bi], wcv[j], qtab);
-                    if (c != 1) {
+                    if (c != 1 && !f.no_cfl) {
                         const int ty = (py0 + n) >> 6, tx = (px0 + x) >> 6;
                         float kX, kB;
                         cfl_factors(f, ty, tx, (b.cfl_zero >> ((ty - (py0 >> 6)) * 5 + (tx - (px0 >> 6)))) & 1u, kX, kB);

@@ -65,6 +65,23 @@ __global__ __launch_bounds__(256) void k_lf_dequant(const LfArgs a) {
     for (int i = 0; i < 3; i++) a.out[i][d] = o[i];
 }
 
+__global__ __launch_bounds__(256) void k_lf_dequant_plain(const int32_t* __restrict__ q, float* __restrict__ out, int H, int W,
+                                                          int64_t out_off, int out_stride, float sd) {
+    const int n = H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
+        out[out_off + (int64_t)y * out_stride + x] = (float)q[i] * sd;  // LFCoefficients.java:66-75
+    }
+}
+
+void launch_lf_dequant_plain(const int32_t* q, float* out, int H, int W, int64_t out_off, int out_stride, float scaled_dequant,
+                             int extra_precision, hipStream_t s) {
+    if (H <= 0 || W <= 0) return;
+    const float sd = scaled_dequant / (float)(1 << extra_precision);
+    const int grid = std::min(4096, (H * W + 255) / 256);
+    hipLaunchKernelGGL(k_lf_dequant_plain, dim3(grid), dim3(256), 0, s, q, out, H, W, out_off, out_stride, sd);
+}
+
 void launch_lf_dequant(const int32_t* const q[3], float* const out[3], int H, int W, int64_t out_off, int out_stride,
                        const float scaled_dequant[3], int extra_precision, float base_corr_x, float base_corr_b,
                        int color_factor, int x_factor_lf, int b_factor_lf, int smooth, hipStream_t s) {

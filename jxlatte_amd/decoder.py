@@ -172,8 +172,7 @@ class DeviceBackend:
         for g in lfgroups:
             fr.setLFGroup(g)
             if g.get("lf_quant") is not None:
-                q = np.ascontiguousarray(np.stack(g["lf_quant"]), np.int32)
-                fr.setLFGroupQuant(g["lfg_y"], g["lfg_x"], q, g["scaled_dequant"], g["extra_precision"], g["x_factor_lf"],
+                fr.setLFGroupQuant(g["lfg_y"], g["lfg_x"], g["lf_quant"], g["scaled_dequant"], g["extra_precision"], g["x_factor_lf"],
                                    g["b_factor_lf"], g["adaptive_smoothing"])
         for pass_, grp, q in groups:
             fr.putGroup(pass_, grp, q)
@@ -443,9 +442,9 @@ class JXLDecoder:
     def _vardct_inputs(self, fr, fuse_xyb):
         """the boundary tensors of one VarDCT frame: (jxl_vardct_params, weights, offsets, LF groups, group iterator)"""
         info, fe = self.info, self.fe
-        if any(fr.jpeg_up_y) or any(fr.jpeg_up_x):
-            raise UnsupportedOperationException("chroma-subsampled VarDCT frames (jpegUpsampling != 0)")
         p = abi.VarDCTParams()
+        for c in range(3):
+            p.jpeg_upsampling_y[c], p.jpeg_upsampling_x[c] = fr.jpeg_up_y[c], fr.jpeg_up_x[c]
         p.width, p.height = fr.padded_width, fr.padded_height
         stages = abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF | (abi.STAGE_XYB if fuse_xyb else 0)
         p.stages = stages
@@ -815,7 +814,7 @@ def load_vardct_frame(source, ctx, transfer=abi.TRANSFER_NONE, out_format=abi.OU
     for g in lfgroups:
         hf.setLFGroup(g)
         if g.get("lf_quant") is not None:
-            hf.setLFGroupQuant(g["lfg_y"], g["lfg_x"], np.ascontiguousarray(np.stack(g["lf_quant"]), np.int32), g["scaled_dequant"],
+            hf.setLFGroupQuant(g["lfg_y"], g["lfg_x"], g["lf_quant"], g["scaled_dequant"],
                                g["extra_precision"], g["x_factor_lf"], g["b_factor_lf"], g["adaptive_smoothing"])
     for pass_, grp, q in groups():
         hf.putGroup(pass_, grp, q)

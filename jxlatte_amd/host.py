@@ -163,7 +163,7 @@ class Frame:
     def setLFGroupQuant(self, lfg_y, lfg_x, lfQuant, scaledDequant, extraPrecision=0, xFactorLF=128, bFactorLF=128,
                         adaptiveSmoothing=True):
         """row f1: hand over the integer LF image of an LF group instead of the dequantised floats"""
-        q = np.ascontiguousarray(lfQuant, np.int32)
+        q = [np.ascontiguousarray(lfQuant[c], np.int32) for c in range(3)]  # planes differ in size when chroma-subsampled
         d = abi.make_lfquant_desc(q, scaledDequant, extraPrecision, xFactorLF, bFactorLF, adaptiveSmoothing, lfg_y, lfg_x)
         self.ctx.call("jxl_vardct_set_lfgroup_lfquant", C.byref(d))
 

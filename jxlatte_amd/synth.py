@@ -278,14 +278,56 @@ def make_vardct_frame(width, height, seed=1234, mix="default", aligned=True, par
                 block_types=bt, mix=mix, seed=seed)
 
 
+def channel_planes(frame):
+    """views of the coefficient planes in each channel's own geometry: for a chroma-subsampled frame channel c occupies
+    the first (H >> sy) * (W >> sx) samples of coeff[c], row stride W >> sx (the layout the oracle reads)"""
+    W, H = frame["width"], frame["height"]
+    p = abi.VarDCTParams.from_buffer_copy(frame["params"])
+    out = []
+    for c in range(3):
+        h, w = H >> p.jpeg_upsampling_y[c], W >> p.jpeg_upsampling_x[c]
+        out.append(frame["coeff"][c].reshape(-1)[:h * w].reshape(h, w))
+    return out, list(p.jpeg_upsampling_y), list(p.jpeg_upsampling_x)
+
+
 def group_view(frame, group):
     """per-group coefficient planes as the reference holds them (HFCoefficients.quantizedCoeffs):
-    returns list of 3 contiguous int32 arrays [gh][gw]."""
+    returns list of 3 contiguous int32 arrays [gh >> sy][gw >> sx]."""
     W, H = frame["width"], frame["height"]
     grs = (W + 255) // 256
     gy, gx = divmod(group, grs)
     y0, x0 = gy * 256, gx * 256
-    return [np.ascontiguousarray(frame["coeff"][c, y0:min(y0 + 256, H), x0:min(x0 + 256, W)]) for c in range(3)]
+    planes, sy, sx = channel_planes(frame)
+    return [np.ascontiguousarray(planes[c][y0 >> sy[c]:min(y0 + 256, H) >> sy[c], x0 >> sx[c]:min(x0 + 256, W) >> sx[c]])
+            for c in range(3)]
+
+
+def make_subsampled(frame, sy, sx):
+    """Turn an all-DCT8 synthetic frame into a chroma-subsampled one (JPEG-recompression geometry, FrameHeader
+    jpegUpsamplingY/X = sy/sx per channel): the varblocks of channel c that survive are those on even cells, and their
+    coefficients / LF samples move onto the channel's own (H >> sy) x (W >> sx) grid. Gab / EPF keep running on the
+    full-size planes after Frame.invertSubsampling."""
+    W, H = frame["width"], frame["height"]
+    assert W % 16 == 0 and H % 16 == 0
+    p = abi.VarDCTParams.from_buffer_copy(frame["params"])
+    out = dict(frame)
+    coeff = np.zeros_like(frame["coeff"])
+    for c in range(3):
+        p.jpeg_upsampling_y[c], p.jpeg_upsampling_x[c] = sy[c], sx[c]
+        h, w = H >> sy[c], W >> sx[c]
+        full = frame["coeff"][c].reshape(H // 8, 8, W // 8, 8)
+        sub = full[::1 << sy[c], :, ::1 << sx[c], :]  # blocks on aligned cells, in their new positions
+        coeff[c].reshape(-1)[:h * w] = np.ascontiguousarray(sub).reshape(h, w).reshape(-1)
+    out["coeff"] = coeff
+    out["params"] = p
+    groups = []
+    for g in frame["lfgroups"]:
+        assert (g["dct_select"] == 0).all(), "make_subsampled needs an all-DCT8 tiling"
+        g2 = dict(g)
+        g2["lf"] = [np.ascontiguousarray(g["lf"][c][::1 << sy[c], ::1 << sx[c]]) for c in range(3)]
+        groups.append(g2)
+    out["lfgroups"] = groups
+    return out
 
 
 def num_groups(frame):

@@ -311,7 +311,17 @@ static jxl_status vardct_group(const orc_vardct_frame* f, int group, float* cons
     /* groupPosInLFGroup (:897) << 5: position in cells inside the LF group */
     const int gposy = (gy - (lfg->lfg_y << 3)) << 5, gposx = (gx - (lfg->lfg_x << 3)) << 5;
     const int cw = lfg->cells_w;
-    const int64_t goff = (int64_t)(gy << 8) * W + (gx << 8); /* groupLocation << 8 (PassGroup.java:203-205) */
+    /* per-channel geometry of chroma-subsampled frames (FrameHeader.jpegUpsamplingY/X; PassGroup.java:213-226) */
+    int sy[3], sx[3], Wc[3], lfw[3], subsampled = 0;
+    int64_t goffc[3];
+    for (int c = 0; c < 3; c++) {
+        sy[c] = p->jpeg_upsampling_y[c];
+        sx[c] = p->jpeg_upsampling_x[c];
+        subsampled |= sy[c] | sx[c];
+        Wc[c] = W >> sx[c];
+        lfw[c] = cw >> sx[c];
+        goffc[c] = (int64_t)((gy << 8) >> sy[c]) * Wc[c] + ((gx << 8) >> sx[c]); /* groupLocation << 8 >> upsampling */
+    }
     jxl_status st = JXL_OK;
 
     float* dq[3];
@@ -343,15 +353,17 @@ static jxl_status vardct_group(const orc_vardct_frame* f, int group, float* cons
         int mw = jxl_tt_mw(tt);
         int dsh = tt->ph >> 3, dsw = tt->pw >> 3;
         for (int c = 0; c < 3; c++) {
+            int sGroupY = groupY >> sy[c], sGroupX = groupX >> sx[c];
+            if (groupY != sGroupY << sy[c] || groupX != sGroupX << sx[c]) continue; /* subsampled block (:292-297) */
             const float* w3 = f->weights + f->woffs[tt->param_index * 3 + c];
             float sfc = p->scale_factor[c] / (float)lfg->hf_mul[posy * cw + posx];
-            int pgy = groupY << 3, pgx = groupX << 3;
+            int pgy = sGroupY << 3, pgx = sGroupX << 3;
             float qbc[3] = {-p->quant_bias[c], 0.0f, p->quant_bias[c]};
             for (int y = 0; y < tt->ph; y++) {
                 for (int x = 0; x < tt->pw; x++) {
                     if (y < dsh && x < dsw) continue;
                     int pY = pgy + y, pX = pgx + x;
-                    int32_t coeff = f->coeff[c][goff + (int64_t)pY * W + pX];
+                    int32_t coeff = f->coeff[c][goffc[c] + (int64_t)pY * Wc[c] + pX];
                     float quant = (coeff > -2 && coeff < 2) ? qbc[coeff + 1]
                                                             : (float)coeff - p->quant_bias_numerator / (float)coeff;
                     int wy = flip ? x : y;
@@ -362,8 +374,8 @@ static jxl_status vardct_group(const orc_vardct_frame* f, int group, float* cons
         }
     }
 
-    /* chromaFromLuma (HFCoefficients.java:146-192); jpegUpsampling is always 0 here */
-    {
+    /* chromaFromLuma (HFCoefficients.java:146-192): skipped for chroma-subsampled frames (:149-151) */
+    if (!subsampled) {
         int th = ceil_div(lfg->cells_h, 8), tw = ceil_div(lfg->cells_w, 8);
         float* xF = (float*)calloc((size_t)th * tw * 2, sizeof(float)); /* xFactors / bFactors, per call */
         float* bF = xF + (size_t)th * tw;
@@ -406,9 +418,12 @@ static jxl_status vardct_group(const orc_vardct_frame* f, int group, float* cons
         int groupY = posy - gposy, groupX = posx - gposx;
         int dsh = tt->ph >> 3, dsw = tt->pw >> 3;
         for (int c = 0; c < 3; c++) {
-            int pgy = groupY << 3, pgx = groupX << 3;
+            int sGroupY = groupY >> sy[c], sGroupX = groupX >> sx[c];
+            if (groupY != sGroupY << sy[c] || groupX != sGroupX << sx[c]) continue;
+            int pgy = sGroupY << 3, pgx = sGroupX << 3;
             const float* dqlf = lfg->lf[c];
-            fdct2d_s(dqlf + (int64_t)posy * cw + posx, cw, dq[c] + pgy * SCR + pgx, SCR, dsh, dsw, ls0, ls1);
+            int sLfgY = posy >> sy[c], sLfgX = posx >> sx[c]; /* :213-214 */
+            fdct2d_s(dqlf + (int64_t)sLfgY * lfw[c] + sLfgX, lfw[c], dq[c] + pgy * SCR + pgx, SCR, dsh, dsw, ls0, ls1);
             for (int y = 0; y < dsh; y++)
                 for (int x = 0; x < dsw; x++) dq[c][(y + pgy) * SCR + x + pgx] *= llf_scale(y, x, dsh, dsw);
         }
@@ -421,8 +436,10 @@ static jxl_status vardct_group(const orc_vardct_frame* f, int group, float* cons
         const jxl_tt_info* tt = &JXL_TT[lfg->dct_select[posy * cw + posx]];
         int groupY = posy - gposy, groupX = posx - gposx;
         for (int c = 0; c < 3; c++) {
-            int ppgy = groupY << 3, ppgx = groupX << 3;
-            st = invert_block(dq[c] + ppgy * SCR + ppgx, SCR, out[c] + goff + (int64_t)ppgy * W + ppgx, W, tt, sb);
+            int sGroupY = groupY >> sy[c], sGroupX = groupX >> sx[c];
+            if (groupY != sGroupY << sy[c] || groupX != sGroupX << sx[c]) continue;
+            int ppgy = sGroupY << 3, ppgx = sGroupX << 3;
+            st = invert_block(dq[c] + ppgy * SCR + ppgx, SCR, out[c] + goffc[c] + (int64_t)ppgy * Wc[c] + ppgx, Wc[c], tt, sb);
             if (st != JXL_OK) goto done;
         }
     }
@@ -730,6 +747,18 @@ jxl_status orc_vardct_frame_run(const orc_vardct_frame* f, void* const out[3]) {
         /* stage tests may feed pixel planes through coeff[] reinterpretation: not supported */
     }
     if (st != JXL_OK) goto done;
+
+    /* Frame.invertSubsampling (Frame.java:457, 681-723): channels decoded at (H >> sy) x (W >> sx) grow to H x W */
+    if (p->stages & JXL_STAGE_IDCT)
+        for (int c = 0; c < 3; c++) {
+            const int sy = p->jpeg_upsampling_y[c], sx = p->jpeg_upsampling_x[c];
+            if (sy < 0 || sx < 0 || sy > 2 || sx > 2) { st = JXL_ERR_INVALID_ARGUMENT; goto done; }
+            if (!sy && !sx) continue;
+            orc_chroma_upsample(buf[c], H >> sy, W >> sx, sx, sy, tmp[c]);
+            float* t = buf[c];
+            buf[c] = tmp[c];
+            tmp[c] = t;
+        }
 
     if ((p->stages & JXL_STAGE_GAB) && p->gab) {
         const float* const ib[3] = {buf[0], buf[1], buf[2]};

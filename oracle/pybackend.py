@@ -20,17 +20,27 @@ class OracleBackend:
 
     def vardct(self, params, weights, woffs, lfgroups, groups):
         H, W = params.height, params.width
+        sy, sx = list(params.jpeg_upsampling_y), list(params.jpeg_upsampling_x)
+        sub = any(sy) or any(sx)
+        # channel c lives in the first (H >> sy) * (W >> sx) samples of its plane, row stride W >> sx
         coeff = np.zeros((3, H, W), np.int32)
+        views = [coeff[c].reshape(-1)[:(H >> sy[c]) * (W >> sx[c])].reshape(H >> sy[c], W >> sx[c]) for c in range(3)]
         cols = (W + 255) // 256
         for pass_, grp, q in groups:
             gy, gx = grp // cols, grp % cols
             for c in range(3):
                 h, w = q[c].shape
-                coeff[c, gy * 256:gy * 256 + h, gx * 256:gx * 256 + w] += q[c]
+                y0, x0 = (gy * 256) >> sy[c], (gx * 256) >> sx[c]
+                views[c][y0:y0 + h, x0:x0 + w] += q[c]
         lfg = []
         for g in lfgroups:
             g = dict(g)
-            if g.get("lf_quant") is not None:
+            if g.get("lf_quant") is not None and sub:
+                # LFCoefficients.java:66-75 only: chroma-from-luma and smoothing do not apply to subsampled frames
+                g["lf"] = [np.ascontiguousarray(g["lf_quant"][c].astype(np.float32) *
+                                                (np.float32(g["scaled_dequant"][c]) / np.float32(1 << g["extra_precision"])))
+                           for c in range(3)]
+            elif g.get("lf_quant") is not None:
                 lf = orc.lf_dequant(np.stack(g["lf_quant"]), g["scaled_dequant"], g["extra_precision"], g["x_factor_lf"],
                                     g["b_factor_lf"], g["adaptive_smoothing"], params.base_corr_x, params.base_corr_b,
                                     params.color_factor)

@@ -58,7 +58,7 @@ def test_transform_type_table_matches_header():
 
 def test_struct_sizes_match_c_layout():
     # computed by hand from the header: all members are 4-byte scalars / arrays
-    assert C.sizeof(abi.VarDCTParams) == 4 * (3 + 3 + 3 + 1 + 2 + 1 + 1 + 3 + 3 + 1 + 1 + 8 + 3 + 3 + 1 + 9 + 3 + 3 + 1 + 2)
+    assert C.sizeof(abi.VarDCTParams) == 4 * (3 + 3 + 3 + 1 + 2 + 1 + 1 + 3 + 3 + 1 + 1 + 8 + 3 + 3 + 1 + 9 + 3 + 3 + 1 + 2 + 6)
     assert C.sizeof(abi.SqueezeParam) == 16
     assert C.sizeof(abi.Channel) == 16
     assert C.sizeof(abi.LFGroupDesc) == 16 + 6 * 8 + 8 + 3 * 8

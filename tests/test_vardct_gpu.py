@@ -57,3 +57,50 @@ def test_frame_parity_epf_iterations(ctx, orc, iters):
     frame = synth.make_vardct_frame(256, 128, seed=11 + iters, mix="default", epf_iters=iters)
     got, exp = run_both(ctx, orc, frame, abi.STAGE_ALL & ~abi.STAGE_OUT)
     assert_bits_equal(got, exp, "epf iters %d" % iters)
+
+
+# ---- row a16: chroma-subsampled (JPEG-recompression) frames -------------------------------------------------------------
+SUBSAMPLINGS = {"420": ((1, 0, 1), (1, 0, 1)), "422": ((0, 0, 0), (1, 0, 1)), "440": ((1, 0, 1), (0, 0, 0)),
+                "luma_sub": ((0, 1, 0), (0, 1, 0))}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", sorted(SUBSAMPLINGS))
+@pytest.mark.parametrize("size", [(64, 32), (272, 48), (528, 272)])
+def test_chroma_subsampled_frame(ctx, orc, mode, size):
+    """IDCT on each channel's own grid, chroma-from-luma skipped, Frame.invertSubsampling, then Gab / EPF on full planes"""
+    sy, sx = SUBSAMPLINGS[mode]
+    base = synth.make_vardct_frame(size[0], size[1], seed=size[0] + len(mode), mix="dct8", xyb=0)
+    fr = synth.make_subsampled(base, sy, sx)
+    for stages in (abi.STAGE_IDCT, abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF):
+        got = host.Frame.from_synth(ctx, fr, stages=stages).decodeFrame()
+        exp = orc.vardct_frame(fr, stages=stages)
+        assert_bits_equal(got, exp, "%s %s stages %d" % (mode, size, stages))
+    # the surviving chroma really differs from the unsubsampled decode (the test would be vacuous otherwise)
+    plain = orc.vardct_frame(base, stages=abi.STAGE_IDCT)
+    assert not np.array_equal(plain[0 if mode != "luma_sub" else 1], exp[0 if mode != "luma_sub" else 1])
+
+
+@pytest.mark.gpu
+def test_chroma_subsampled_lfquant_and_errors(ctx, orc):
+    from jxlatte_amd import _lib
+    base = synth.make_vardct_frame(64, 32, seed=5, mix="dct8", xyb=0)
+    fr = synth.make_subsampled(base, (1, 0, 1), (1, 0, 1))
+    f = host.Frame.from_synth(ctx, fr, stages=abi.STAGE_IDCT)
+    q = [np.ascontiguousarray(np.rint(g * 64).astype(np.int32)) for g in fr["lfgroups"][0]["lf"]]
+    with pytest.raises(_lib.InvalidBitstreamException):  # LFCoefficients.java:36-37
+        d = abi.LFQuantDesc()
+        d.cells_h, d.cells_w = 4, 8
+        for c in range(3):
+            d.lf_quant[c] = abi.iptr(q[c])
+            d.scaled_dequant[c] = 1.0 / 64
+        d.adaptive_smoothing = 1
+        ctx.call("jxl_vardct_set_lfgroup_lfquant", __import__("ctypes").byref(d))
+    d.adaptive_smoothing = 0
+    ctx.call("jxl_vardct_set_lfgroup_lfquant", __import__("ctypes").byref(d))
+    got = f.decodeFrame()
+    fr2 = dict(fr)
+    g2 = dict(fr["lfgroups"][0])
+    g2["lf"] = [np.ascontiguousarray(a.astype(np.float32) * np.float32(1.0 / 64)) for a in q]
+    fr2["lfgroups"] = [g2]
+    assert_bits_equal(got, orc.vardct_frame(fr2, stages=abi.STAGE_IDCT), "subsampled LF quant")
