@@ -153,6 +153,8 @@ jxf_dec* jxf_open(const uint8_t* data, size_t size, char* err, size_t err_len) {
         d->br = BitReader(d->codestream.data(), d->codestream.size());
         d->ih.read(d->br, d->level);
         if (d->ih.extra.size() > JXF_MAX_EXTRA) throw UnsupportedError("more than 16 extra channels");
+        // every plane of a frame is materialised: refuse images whose planes alone would need tens of GB
+        if ((int64_t)d->ih.width * d->ih.height > (1ll << 28)) throw UnsupportedError("image larger than 2^28 pixels");
     } catch (const std::exception& e) {
         if (err && err_len) snprintf(err, err_len, "%s", e.what());
         return nullptr;
@@ -213,6 +215,7 @@ int32_t jxf_next_frame(jxf_dec* d, const jxf_hooks* hooks) {
         d->frame = std::make_unique<Frame>();
         Frame& f = *d->frame;
         f.read_header(d->br, d->ih);
+        if ((int64_t)f.padded_w * f.padded_h > (1ll << 28)) throw UnsupportedError("frame larger than 2^28 pixels");
         HookCtx hc{hooks, &d->error};
         TransformHooks th;
         th.user = &hc;

@@ -115,6 +115,33 @@ def test_frontend_rejects_garbage():
         fe.next_frame(None, None)
 
 
+def test_frontend_survives_mutated_input(orc):
+    """corrupt bitstreams end in FrontendError (or decode to something), never in a crash; the sanitizer build of the same
+    loop is `make -C jxlatte_amd/frontend fuzz`"""
+    rng = np.random.default_rng(2026)
+    sq, rct = oracle_hooks(orc)
+    for name in ("art", "white", "blendmodes_5", "lenna"):
+        good = bytearray(open(path(name), "rb").read())
+        for _ in range(40):
+            bad = bytearray(good)
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                for _k in range(int(rng.integers(1, 4))):
+                    bad[int(rng.integers(0, min(len(bad), 300)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                bad = bad[:int(rng.integers(1, len(bad)))]
+            else:
+                pos = int(rng.integers(0, len(bad)))
+                bad[pos:pos + 8] = bytes(rng.integers(0, 256, min(8, len(bad) - pos)).astype(np.uint8))
+            try:
+                fe = frontend.Frontend(bytes(bad))
+                n = 0
+                while fe.next_frame(sq, rct) is not None and n < 20:
+                    n += 1
+            except (frontend.FrontendError, RuntimeError, ValueError):
+                pass
+
+
 def test_frame_level_modular_needs_hooks():
     """no CPU fallback for the frame-level inverse Squeeze / RCT: without hooks the front-end refuses"""
     for name in ("art", "quilt"):  # art.jxl: frame-level RCT; quilt.jxl: frame-level Squeeze (16 steps)
