@@ -18,6 +18,11 @@ SOURCES = ["k_idct.hip", "k_restore.hip", "k_restore_fused.hip", "k_modular.hip"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
+# per-file additions (environment override for experiments: JXL_EXTRA_<stem>="-flag -flag")
+# k_restore_fused: hipcc's SLP vectoriser packs the EPF distance terms into v_pk_* pairs but pays for it with ~50 register
+# moves and 35 v_and (abs) per channel iteration; scalar code with free |x| source modifiers is 12 % faster (measured).
+# k_idct: the IDCT cores use explicit packed vectors; auto-SLP on the 8x8 special transforms costs 19 % (same symptom).
+EXTRA = {"k_restore_fused": ["-fno-slp-vectorize"], "k_idct": ["-fno-slp-vectorize"]}
 
 
 def _deps():
@@ -35,7 +40,10 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            jobs.append([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+            stem = src.replace(".hip", "")
+            extra = os.environ.get("JXL_EXTRA_" + stem, None)
+            extra = extra.split() if extra is not None else EXTRA.get(stem, [])
+            jobs.append([HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
     if jobs:
         def run(cmd):
             if verbose:
