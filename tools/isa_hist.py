@@ -4,7 +4,7 @@ import re, subprocess, sys
 from collections import Counter
 src, pat = sys.argv[1], sys.argv[2]
 minb = int(sys.argv[3]) if len(sys.argv) > 3 else 60
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-S",
                        "--cuda-device-only", src, "-o", "/tmp/isa.s"], stderr=subprocess.DEVNULL)
 lines = open("/tmp/isa.s").read().split("\n")
 start = end = None
