@@ -129,6 +129,13 @@ typedef struct jxf_patch_view { /* J/frame/features/Patch.java */
     const int32_t* blend;                            /* n_positions x n_blend x (mode, alpha, clamp) */
 } jxf_patch_view;
 
+typedef struct jxf_spline_view { /* one spline of J/frame/features/spline/SplinesBundle.java */
+    int32_t quant_adjust;      /* SplinesBundle.quantAdjust (frame-wide) */
+    int32_t n_control;
+    const int32_t* control;    /* n_control x (y, x) */
+    const int32_t* coeff;      /* [4][32]: X, Y, B, sigma */
+} jxf_spline_view;
+
 /* Parses the container (if any) and the image header. data is copied. Returns NULL and fills err on failure. */
 jxf_dec* jxf_open(const uint8_t* data, size_t size, char* err, size_t err_len);
 void jxf_close(jxf_dec* d);
@@ -146,6 +153,9 @@ int32_t jxf_get_lfgroup(const jxf_dec* d, int32_t index, jxf_lfgroup_view* out);
 int32_t jxf_get_coeffs(const jxf_dec* d, int32_t pass, int32_t group, jxf_coeff_view* out);
 int32_t jxf_get_quant_params(const jxf_dec* d, int32_t index, jxf_quant_view* out);
 int32_t jxf_get_patch(const jxf_dec* d, int32_t index, jxf_patch_view* out);
+/* number of splines of the current frame, and one of them */
+int32_t jxf_num_splines(const jxf_dec* d);
+int32_t jxf_get_spline(const jxf_dec* d, int32_t index, jxf_spline_view* out);
 /* channel i of the frame-level modular stream after its inverse transforms */
 int32_t jxf_get_modular_channel(const jxf_dec* d, int32_t index, jxf_chan* out);
 

@@ -155,6 +155,145 @@ def _to_linear(buf, tf):
     raise ValueError("Invalid transfer function")
 
 
+# ---- splines (J/frame/features/spline/Spline.java): host-side feature, as in the reference ------------------------------
+_SQRT_H = F(math.sqrt(0.5))
+_SQRT_F = F(math.sqrt(0.125))
+
+
+def _erf(z):
+    """MathHelper.erf (MathHelper.java:40-66), vectorised float32 with the reference's operation order"""
+    z = z.astype(F)
+    az = np.abs(z)
+    t = (F(1) / (az * F(0.5) + F(1))).astype(F)
+    u = t * F(0.17087277) - F(0.82215223)
+    for cst, sign in ((1.48851587, 1), (1.13520398, -1), (0.27886807, 1), (0.18628806, -1), (0.09678418, 1), (0.37409196, 1),
+                      (1.00002368, 1)):
+        u = (t * u + F(cst)).astype(F) if sign > 0 else (t * u - F(cst)).astype(F)
+    u = (t * u - F(1.26551223)).astype(F)
+    big = (F(1) - t * np.exp((-(z * z) + u).astype(np.float64)).astype(F)).astype(F)
+    t2 = (F(1) / (az * F(0.47047) + F(1))).astype(F)
+    u2 = (t2 * ((t2 * ((t2 * F(0.7478556) - F(0.0958798)).astype(F)) + F(0.3480242)).astype(F))).astype(F)
+    small = (F(1) - u2 * np.exp((-(z * z)).astype(np.float64)).astype(F)).astype(F)
+    a = np.where(az > F(1e-4), big, small).astype(F)
+    return np.where(z < 0, -a, a).astype(F)
+
+
+def _spline_arcs(control):
+    """Spline.upsampleControlPoints + computeIntermediarySamples(1.0f): list of (y, x, arcLength)"""
+    cp = [(int(y), int(x)) for y, x in control]
+    if len(cp) == 1:
+        uy, ux = [F(cp[0][0])], [F(cp[0][1])]
+    else:
+        ext = [(cp[0][0] * 2 - cp[1][0], cp[0][1] * 2 - cp[1][1])] + cp + [(cp[-1][0] * 2 - cp[-2][0], cp[-1][1] * 2 - cp[-2][1])]
+        n = 16 * (len(ext) - 3) + 1
+        uy, ux = [F(0)] * n, [F(0)] * n
+        for i in range(len(ext) - 3):
+            pY = [F(ext[i + k][0]) for k in range(4)]
+            pX = [F(ext[i + k][1]) for k in range(4)]
+            uy[i << 4], ux[i << 4] = pY[1], pX[1]
+            t = [F(0)] * 4
+            dY, dX = [F(0)] * 3, [F(0)] * 3
+            for k in range(3):
+                dY[k], dX[k] = F(pY[k + 1] - pY[k]), F(pX[k + 1] - pX[k])
+                t[k + 1] = F(t[k] + F(math.pow(float(F(F(dY[k] * dY[k]) + F(dX[k] * dX[k]))), 0.25)))
+            for step in range(1, 16):
+                knot = F(t[1] + F(F(F(0.0625) * F(step)) * F(t[2] - t[1])))
+                aY, aX = [F(0)] * 3, [F(0)] * 3
+                with np.errstate(all="ignore"):
+                    for k in range(3):
+                        f = F(F(knot - t[k]) / F(t[k + 1] - t[k]))
+                        aY[k], aX[k] = F(F(dY[k] * f) + pY[k]), F(F(dX[k] * f) + pX[k])
+                    bY, bX = [F(0)] * 2, [F(0)] * 2
+                    for k in range(2):
+                        f = F(F(knot - t[k]) / F(t[k + 2] - t[k]))
+                        bY[k], bX[k] = F(F(F(aY[k + 1] - aY[k]) * f) + aY[k]), F(F(F(aX[k + 1] - aX[k]) * f) + aX[k])
+                    f = F(F(knot - t[1]) / F(t[2] - t[1]))
+                    uy[i * 16 + step] = F(F(F(bY[1] - bY[0]) * f) + bY[0])
+                    ux[i * 16 + step] = F(F(F(bX[1] - bX[0]) * f) + bX[0])
+        uy[-1], ux[-1] = F(cp[-1][0]), F(cp[-1][1])
+    rd = F(1.0)
+    cy, cx = uy[0], ux[0]
+    nxt = 0
+    arcs = [(cy, cx, rd)]
+    while nxt < len(uy):
+        py, px = cy, cx
+        acc = F(0)
+        while True:
+            if nxt >= len(uy):
+                arcs.append((py, px, acc))
+                break
+            ny, nx = uy[nxt], ux[nxt]
+            dy, dx = F(ny - py), F(nx - px)
+            to_next = F(math.sqrt(float(F(F(dy * dy) + F(dx * dx)))))
+            if F(acc + to_next) >= rd:
+                f = F(F(rd - acc) / to_next)
+                cy, cx = F(F(dy * f) + py), F(F(dx * f) + px)
+                arcs.append((cy, cx, rd))
+                break
+            acc = F(acc + to_next)
+            py, px = ny, nx
+            nxt += 1
+    return arcs
+
+
+def _fourier_ict(coeffs, t):
+    total = F(_SQRT_H * coeffs[0])
+    for i in range(1, 32):
+        total = F(total + F(coeffs[i] * F(math.cos(i * (math.pi / 32.0) * (float(t) + 0.5)))))
+    return total
+
+
+def render_splines(buffers, splines, base_corr_x, base_corr_b, width, height):
+    """Frame.renderSplines + Spline.renderSpline (Spline.java:157-201). The reference never stores the spline index
+    (Spline.java:22-24), so every spline is drawn with the coefficients of spline 0; `MathHelper.max(float...)` returns the
+    minimum (MathHelper.java:190-195). Both restated as they are."""
+    if not splines:
+        return
+    s0 = splines[0]
+    qa = F(F(s0["quant_adjust"]) / F(8))
+    inv_qa = F(F(1) / F(F(1) + qa)) if qa >= 0 else F(F(1) - qa)
+    adj = [F(F(0.005939697) * inv_qa), F(F(0.106066017) * inv_qa), F(F(0.098994949) * inv_qa), F(F(0.47135738) * inv_qa)]
+    cY = [F(F(v) * adj[1]) for v in s0["coeff"][1]]
+    cX = [F(F(F(v) * adj[0]) + F(F(base_corr_x) * cY[i])) for i, v in enumerate(s0["coeff"][0])]
+    cB = [F(F(F(v) * adj[2]) + F(F(base_corr_b) * cY[i])) for i, v in enumerate(s0["coeff"][2])]
+    cS = [F(F(v) * adj[3]) for v in s0["coeff"][3]]
+    for sp in splines:
+        arcs = _spline_arcs(sp["control"])
+        rd = F(1.0)
+        arc_len = F(F(F(len(arcs)) - F(2)) * rd + arcs[-1][2])
+        if arc_len <= 0:
+            continue
+        for i, (ay, ax, alen) in enumerate(arcs):
+            prog = min(F(1.0), F(F(F(i) * rd) / arc_len))
+            t = F(F(31) * prog)
+            vals = [F(_fourier_ict(c, t) * alen) for c in (cX, cY, cB)]
+            sigma = _fourier_ict(cS, t)
+            with np.errstate(all="ignore"):
+                inv_sigma = F(F(1) / sigma)
+                max_color = min(F(0.01), vals[0], vals[1], vals[2])  # MathHelper.max(float...) is a minimum
+                md = F(math.sqrt(float(F(F(F(-2) * sigma) * sigma * F(F(F(math.log(0.1)) * F(3)) - max_color))))) \
+                    if F(F(F(-2) * sigma) * sigma * F(F(F(math.log(0.1)) * F(3)) - max_color)) >= 0 else F(np.nan)
+            if not np.isfinite(md):
+                continue  # (int)(NaN + 0.5f) == 0 for both bounds of an empty-ish box; nothing sensible to draw
+
+            def rnd(v):
+                return int(np.trunc(np.clip(F(v + F(0.5)), -2**31, 2**31 - 1)))
+            xb, xe = max(0, rnd(F(ax - md))), min(width - 1, rnd(F(ax + md)))
+            yb, ye = max(0, rnd(F(ay - md))), min(height - 1, rnd(F(ay + md)))
+            if xb > xe or yb > ye:
+                continue
+            ys = np.arange(yb, ye + 1, dtype=F)[:, None]
+            xs = np.arange(xb, xe + 1, dtype=F)[None, :]
+            dy, dx = (ys - ay).astype(F), (xs - ax).astype(F)
+            dist = np.sqrt(((dy * dy).astype(F) + (dx * dx).astype(F)).astype(np.float64)).astype(F)
+            with np.errstate(all="ignore"):
+                fac = _erf(((F(0.5) * dist).astype(F) + _SQRT_F).astype(F) * inv_sigma)
+                fac = (fac - _erf(((F(0.5) * dist).astype(F) - _SQRT_F).astype(F) * inv_sigma)).astype(F)
+                for c in range(3):
+                    extra = ((((F(0.25) * vals[c]) * sigma).astype(F) * fac).astype(F) * fac).astype(F)
+                    buffers[c][yb:ye + 1, xb:xe + 1] = (buffers[c][yb:ye + 1, xb:xe + 1] + extra).astype(F)
+
+
 # ---- backends -------------------------------------------------------------------------------------------------
 class DeviceBackend:
     """the product backend: HIP kernels through the C-ABI (jxlatte_amd._lib / host). No CPU fallback."""
@@ -649,8 +788,6 @@ class JXLDecoder:
             colors = self._colors(fr)
             simple = fr.upsampling == 1 and not fr.num_patches and not fr.has_splines and not fr.has_noise and \
                 not (fr.save_before_ct and not fr.is_last)
-            if fr.has_splines:
-                raise UnsupportedOperationException("splines")
             ph, pw = fr.padded_height, fr.padded_width
             buffers = []
             for c in range(colors + info.num_extra):
@@ -710,6 +847,10 @@ class JXLDecoder:
             if save and fr.save_before_ct:
                 self.reference[fr.save_as_reference] = [b.copy() for b in buffers]
             self._patches(fr, buffers, colors)
+            if fr.has_splines:  # Frame.renderSplines (host-side, as in the reference)
+                for c in range(3):
+                    buffers[c] = self._to_float(buffers[c], info.bits_per_sample).copy()
+                render_splines(buffers, self.fe.splines(), fr.base_corr_x, fr.base_corr_b, buffers[0].shape[1], buffers[0].shape[0])
             if noise is not None:
                 planes = np.stack([self._to_float(buffers[c], info.bits_per_sample) for c in range(3)])
                 planes = be.noise_add(planes, noise, np.array(fr.noise, F), fr.base_corr_x, fr.base_corr_b)

@@ -86,6 +86,10 @@ class PatchView(C.Structure):
                 ("positions", C.POINTER(i32)), ("blend", C.POINTER(i32))]
 
 
+class SplineView(C.Structure):
+    _fields_ = [("quant_adjust", i32), ("n_control", i32), ("control", C.POINTER(i32)), ("coeff", C.POINTER(i32))]
+
+
 class FrontendError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("jxf status %d: %s" % (status, msg))
@@ -104,6 +108,8 @@ SIGNATURES = {
     "jxf_get_coeffs": (i32, [C.c_void_p, i32, i32, C.POINTER(CoeffView)]),
     "jxf_get_quant_params": (i32, [C.c_void_p, i32, C.POINTER(QuantView)]),
     "jxf_get_patch": (i32, [C.c_void_p, i32, C.POINTER(PatchView)]),
+    "jxf_num_splines": (i32, [C.c_void_p]),
+    "jxf_get_spline": (i32, [C.c_void_p, i32, C.POINTER(SplineView)]),
     "jxf_get_modular_channel": (i32, [C.c_void_p, i32, C.POINTER(Chan)]),
 }
 
@@ -251,6 +257,14 @@ class Frontend:
         self._check(self.lib.jxf_get_patch(self.h, index, C.byref(v)))
         return dict(ref=v.ref, x0=v.x0, y0=v.y0, w=v.w, h=v.h, positions=_np(v.positions, (v.n_positions, 2)),
                     blend=_np(v.blend, (v.n_positions, v.n_blend, 3)))
+
+    def splines(self):
+        out = []
+        for i in range(self.lib.jxf_num_splines(self.h)):
+            v = SplineView()
+            self._check(self.lib.jxf_get_spline(self.h, i, C.byref(v)))
+            out.append(dict(quant_adjust=v.quant_adjust, control=_np(v.control, (v.n_control, 2)), coeff=_np(v.coeff, (4, 32))))
+        return out
 
     def modular_channel(self, index):
         c = Chan()

@@ -322,6 +322,18 @@ int32_t jxf_get_patch(const jxf_dec* dc, int32_t index, jxf_patch_view* o) {
     return JXF_OK;
 }
 
+int32_t jxf_num_splines(const jxf_dec* d) { return d && d->frame ? (int32_t)d->frame->splines.size() : 0; }
+
+int32_t jxf_get_spline(const jxf_dec* d, int32_t index, jxf_spline_view* o) {
+    if (!d || !o || !d->frame || index < 0 || index >= (int32_t)d->frame->splines.size()) return JXF_ERR_ARGUMENT;
+    const SplineData& sp = d->frame->splines[index];
+    o->quant_adjust = d->frame->spline_quant_adjust;
+    o->n_control = (int32_t)sp.control.size() / 2;
+    o->control = sp.control.data();
+    o->coeff = &sp.coeff[0][0];
+    return JXF_OK;
+}
+
 int32_t jxf_get_modular_channel(const jxf_dec* d, int32_t index, jxf_chan* o) {
     if (!d || !o || !d->frame) return JXF_ERR_STATE;
     auto& ch = d->frame->global_modular.channels;

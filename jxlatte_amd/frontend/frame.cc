@@ -144,25 +144,45 @@ void Frame::read_lf_global(BitReader& br) {
     if (fh.flags & kSplines) {
         if (ih->colour_channels() < 3) throw BitstreamError("Cannot do splines in grayscale");
         has_splines = true;
-        // SplinesBundle.java: parsed to stay in sync with the bitstream; rendering splines is not part of this path
+        // SplinesBundle.java:22-73
         auto code = std::make_shared<EntropyCode>();
         code->read(br, 6);
         EntropyDecoder dec(code);
         const int64_t n = 1 + (int64_t)dec.read(br, 2);
-        if (n > (1 << 24)) throw BitstreamError("too many splines");
+        if (n > (1 << 16)) throw BitstreamError("too many splines");
+        splines.assign((size_t)n, SplineData());
+        std::vector<int32_t> sy(n), sx(n);
         for (int64_t i = 0; i < n; i++) {
-            dec.read(br, 1);
-            dec.read(br, 1);
-        }
-        dec.read(br, 0);
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t cc = 1 + (int64_t)dec.read(br, 3);
-            if (cc > (1 << 24)) throw BitstreamError("too many spline control points");
-            for (int64_t j = 0; j + 1 < cc; j++) {
-                dec.read(br, 4);
-                dec.read(br, 4);
+            int32_t x = (int32_t)dec.read(br, 1), y = (int32_t)dec.read(br, 1);
+            if (i != 0) {
+                x = unpack_signed((uint32_t)x) + sx[i - 1];
+                y = unpack_signed((uint32_t)y) + sy[i - 1];
             }
-            for (int j = 0; j < 128; j++) dec.read(br, 5);
+            sx[i] = x;
+            sy[i] = y;
+        }
+        spline_quant_adjust = unpack_signed(dec.read(br, 0));
+        for (int64_t i = 0; i < n; i++) {
+            SplineData& sp = splines[i];
+            const int64_t cc = 1 + (int64_t)dec.read(br, 3);
+            if (cc > (1 << 20)) throw BitstreamError("too many spline control points");
+            std::vector<int32_t> dx(cc - 1), dy(cc - 1);
+            for (int64_t j = 0; j + 1 < cc; j++) {
+                dx[j] = unpack_signed(dec.read(br, 4));
+                dy[j] = unpack_signed(dec.read(br, 4));
+            }
+            int32_t cy = sy[i], cx = sx[i], ddy = 0, ddx = 0;
+            sp.control = {cy, cx};
+            for (int64_t j = 1; j < cc; j++) {
+                ddy += dy[j - 1];
+                ddx += dx[j - 1];
+                cy += ddy;
+                cx += ddx;
+                sp.control.push_back(cy);
+                sp.control.push_back(cx);
+            }
+            for (int k = 0; k < 4; k++)
+                for (int j = 0; j < 32; j++) sp.coeff[k][j] = unpack_signed(dec.read(br, 5));
         }
         dec.check_final("splines");
     }

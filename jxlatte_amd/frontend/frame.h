@@ -28,6 +28,11 @@ struct Patch {  // J/frame/features/Patch.java
     std::vector<std::vector<PatchBlend>> blend;     // [position][1 + extra]
 };
 
+struct SplineData {  // J/frame/features/spline/SplinesBundle.java
+    std::vector<int32_t> control;  // (y, x) pairs
+    int32_t coeff[4][32];           // X, Y, B, sigma
+};
+
 struct QuantParams {  // one of the 17 parameter sets of J/frame/vardct/HFGlobal.java (DCTParams)
     int mode = 0;  // TransformType.MODE_*: 0 library default
     float denominator = 1.0f;
@@ -68,6 +73,8 @@ struct Frame {
     // LfGlobal
     std::vector<Patch> patches;
     bool has_splines = false;
+    int32_t spline_quant_adjust = 0;
+    std::vector<SplineData> splines;
     bool has_noise = false;
     float noise[8] = {0};
     float lf_dequant[3] = {1.0f / 4096.0f, 1.0f / 512.0f, 1.0f / 256.0f};

@@ -19,7 +19,7 @@ from jxlatte_amd.decoder import JXLDecoder, PNGWriter, UnsupportedOperationExcep
 
 SAMPLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "samples")
 ALL = ["art", "quilt", "white", "blendmodes_5", "wb-rainbow", "lenna", "bbb", "patches-lossless", "bench"]
-DECODABLE = ["art", "quilt", "white", "blendmodes_5", "lenna", "bbb", "patches-lossless", "bench"]
+DECODABLE = ["art", "quilt", "white", "blendmodes_5", "wb-rainbow", "lenna", "bbb", "patches-lossless", "bench"]
 
 
 def path(name):
@@ -220,9 +220,18 @@ def test_decode_sample_oracle_backend(oracle_backend, name):
         assert np.corrcoef(g[:, :-1].ravel(), g[:, 1:].ravel())[0, 1] > 0.97
 
 
-def test_unsupported_is_reported_not_faked(oracle_backend):
-    with pytest.raises(UnsupportedOperationException):
-        decode("wb-rainbow", oracle_backend)  # splines
+def test_wb_rainbow_exercises_every_feature_stage(oracle_backend):
+    """352 bytes: 5 modular frames with 2x upsampling, noise, two splines, cropped frames blended with modes ADD / BLEND
+    onto an RGBA canvas -- rows f3 / f4 on a real bitstream"""
+    dec, img = decode("wb-rainbow", oracle_backend)
+    assert len(dec.stats) == 5 and img.hasAlpha() and (img.getWidth(), img.getHeight()) == (2048, 1152)
+    rgb = np.stack(img.buffer[:3])
+    assert rgb.dtype == np.float32 and 0.2 < float(rgb.mean()) < 0.8
+    # the rainbow: every hue sextant is present among saturated pixels
+    mx, mn = rgb.max(0), rgb.min(0)
+    sat = (mx - mn) > 0.5
+    arg = rgb.argmax(0)[sat]
+    assert all((arg == c).mean() > 0.1 for c in range(3))
 
 
 # ---- device vs oracle on real files (GPU) --------------------------------------------------------------------
