@@ -1,0 +1,46 @@
+package com.traneptora.jxlatte.gpu;
+
+import java.nio.ByteBuffer;
+
+/**
+ * JNI mirror of include/jxlatte_amd.h for the jxlatte Java host (row f4 of the scope table).
+ *
+ * NOT COMPILED OR TESTED IN THIS REPOSITORY: the build image has no JDK (no javac, no jni.h). It is the binding a jxlatte
+ * maintainer adds; INTEGRATION.md lists the five call sites of the reference it is used from. All bulk data crosses as
+ * DIRECT ByteBuffers in native byte order because Java float[][] / int[][] rows are separate heap arrays.
+ */
+public final class NativeBackend implements AutoCloseable {
+    static {
+        System.loadLibrary("jxlatte_amd_jni"); // links libjxlatte_amd.so
+    }
+
+    private long ctx; // jxl_ctx*
+
+    public NativeBackend(int device) {
+        ctx = create(device);
+    }
+
+    @Override
+    public void close() {
+        destroy(ctx);
+        ctx = 0;
+    }
+
+    private static native long create(int device);                 // jxl_ctx_create
+    private static native void destroy(long ctx);                  // jxl_ctx_destroy
+
+    /** params: struct jxl_vardct_params packed by the caller (4-byte fields, C layout). */
+    public native void beginFrame(ByteBuffer params);              // jxl_vardct_begin_frame
+    public native void setWeights(ByteBuffer weights, int[] offs); // jxl_vardct_set_weights
+    public native void setLFGroup(int lfgY, int lfgX, int cellsH, int cellsW, ByteBuffer dctSelect, ByteBuffer hfMul,
+        ByteBuffer sharpness, ByteBuffer xFromY, ByteBuffer bFromY, ByteBuffer blockYX, int nBlocks,
+        ByteBuffer lfX, ByteBuffer lfY, ByteBuffer lfB);           // jxl_vardct_set_lfgroup
+    public native void setLFGroupQuant(int lfgY, int lfgX, int cellsH, int cellsW, ByteBuffer qX, ByteBuffer qY, ByteBuffer qB,
+        int extraPrecision, float[] scaledDequant, int xFactorLF, int bFactorLF, boolean adaptiveSmoothing); // ..._lfquant
+    public native void putGroup(int pass, int group, ByteBuffer qX, ByteBuffer qY, ByteBuffer qB, int strideX, int strideY,
+        int strideB);                                              // jxl_vardct_put_group
+    public native void finishFrame(ByteBuffer outX, ByteBuffer outY, ByteBuffer outB, long stride); // jxl_vardct_finish_frame
+    /** channels: one direct buffer per encoded channel; squeezeParams: 4 ints per step. */
+    public native void modularApply(ByteBuffer[] chans, int[] widths, int[] heights, int[] squeezeParams, int rctType,
+        int rctBegin, ByteBuffer[] out, int[] outWidths, int[] outHeights); // jxl_modular_apply
+}
