@@ -61,6 +61,51 @@ __device__ __forceinline__ int32_t tend_apply(int32_t a, const TendPre& t) {
 
 __device__ __forceinline__ int32_t tendency(int32_t a, int32_t b, int32_t c) { return tend_apply(a, tend_pre(b, c)); }
 
+// Short form of tend_apply for the serial chain. With d = 2(a-b) and e = 2(b-c) both even,
+//   "if (x - (x&1) > d) x = d + 1; if (x + (x&1) > e) x = e"  ==  x = min(min(x, d + 1), e)
+//   "if (x + (x&1) < d) x = d - 1; if (x - (x&1) < e) x = e"  ==  x = max(max(x, d - 1), e)
+// (rounding x to the even number below / above and comparing with an even bound is the same as comparing x with the bound
+// +-1; checked exhaustively on small ranges and on 10^7 random triples, tests/test_oracle_kats.py). The identities need
+// d +- 1 and x +- 1 not to wrap, which holds whenever |a-b| and |b-c| are below 2^29; `unsafe` collects the lanes where
+// that is not guaranteed and the caller redoes those steps with tend_apply. The two candidate quotients (+6 / -6) are
+// formed side by side, so no comparison sits in front of the division: ~13 dependent instructions instead of ~25.
+struct TendFast {
+    int32_t base_p6, base_m6;  // -3c - b + 6, -3c - b - 6
+    int32_t e, twob, b;
+    int32_t ge, le;            // all-ones / zero masks of b >= c, b <= c: the selection below is pure VALU bit logic,
+                               // no v_cmp -> SGPR -> s_and -> v_cndmask round trips on the serial chain
+    bool unsafe;
+};
+
+__device__ __forceinline__ TendFast tend_fast_pre(int32_t b, int32_t c) {
+    TendFast t;
+    const int32_t base = wsub(wmul(-3, c), b);
+    t.base_p6 = wadd(base, 6);
+    t.base_m6 = wsub(base, 6);
+    t.e = wmul(2, wsub(b, c));
+    t.twob = wmul(2, b);
+    t.b = b;
+    t.ge = b >= c ? -1 : 0;
+    t.le = b <= c ? -1 : 0;
+    t.unsafe = (uint32_t)wsub(b, c) + 0x20000000u >= 0x40000000u;
+    return t;
+}
+
+__device__ __forceinline__ int32_t tend_fast_apply(int32_t a, const TendFast& t, bool& unsafe) {
+    const int32_t a4 = wmul(4, a);
+    const int32_t x6 = wadd(a4, t.base_p6) / 12, xm6 = wadd(a4, t.base_m6) / 12;
+    const int32_t d = wsub(wmul(2, a), t.twob);
+    const int32_t xd = min(min(x6, wadd(d, 1)), t.e);
+    const int32_t xi = max(max(xm6, wsub(d, 1)), t.e);
+    // inside the safe range a - b cannot wrap, so its sign is the comparison: lt = a < b, gt = a > b as masks
+    const int32_t amb = wsub(a, t.b);
+    const int32_t lt = amb >> 31, gt = wsub(t.b, a) >> 31;
+    const int32_t dec = t.ge & ~lt;         // b >= c && a >= b
+    const int32_t inc = t.le & ~gt & ~dec;  // else b <= c && a <= b
+    unsafe = unsafe || t.unsafe || ((uint32_t)amb + 0x20000000u >= 0x40000000u);
+    return (xd & dec) | (xi & inc);
+}
+
 // One squeeze step is ONE launch over all of its channels: blockIdx.y selects the channel descriptor.
 // (SqueezeBatch is declared in jxl_internal.h.)
 
@@ -78,14 +123,26 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
     constexpr int RV = 8;
     int32_t top = 0;
     int32_t a = rh > 0 ? avg[x] : 0;
+    // software pipeline: the loads of chunk k+1 are issued before the serial chain of chunk k runs, so a lone wave (this
+    // step has far fewer waves than the chip has SIMDs) does not sit in s_waitcnt for a full memory round trip per chunk
+    int32_t rr_n[RV], na_n[RV];
+    auto fetch = [&](int yb, int32_t* r_, int32_t* n_) {
+#pragma unroll
+        for (int i = 0; i < RV; i++) {
+            const int y = yb + i;
+            r_[i] = y < rh ? res[(int64_t)y * w + x] : 0;
+            n_[i] = (y < rh && y + 1 < ah) ? avg[(int64_t)(y + 1) * w + x] : 0;
+        }
+    };
+    fetch(0, rr_n, na_n);
     for (int y0 = 0; y0 < rh; y0 += RV) {
         int32_t rr[RV], na[RV];
 #pragma unroll
         for (int i = 0; i < RV; i++) {
-            const int y = y0 + i;
-            rr[i] = y < rh ? res[(int64_t)y * w + x] : 0;
-            na[i] = (y < rh && y + 1 < ah) ? avg[(int64_t)(y + 1) * w + x] : 0;
+            rr[i] = rr_n[i];
+            na[i] = na_n[i];
         }
+        if (y0 + RV < rh) fetch(y0 + RV, rr_n, na_n);
         // everything that does not depend on the recurrence first
         int32_t av[RV + 1];
         TendPre tp[RV];
@@ -98,13 +155,28 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
         }
         if (y0 + RV <= rh) {  // full chunk: no guards on the serial chain, stores after it
             int32_t o1[RV], o2[RV];
+            TendFast tf[RV];
+#pragma unroll
+            for (int i = 0; i < RV; i++) tf[i] = tend_fast_pre(av[i], av[i + 1]);
+            const int32_t top0 = y0 > 0 ? top : av[0];  // the first pair of a column uses its own average as `left`
+            top = top0;
+            bool unsafe = false;
 #pragma unroll
             for (int i = 0; i < RV; i++) {
-                const int32_t t = (y0 + i) > 0 ? top : av[i];
-                const int32_t diff = wadd(rr[i], tend_apply(t, tp[i]));
+                const int32_t diff = wadd(rr[i], tend_fast_apply(top, tf[i], unsafe));
                 o1[i] = wadd(av[i], diff / 2);
                 o2[i] = wsub(o1[i], diff);
                 top = o2[i];
+            }
+            if (__builtin_expect(__any(unsafe), 0)) {  // operands near the int32 limits: exact long form for this chunk
+                top = top0;
+#pragma unroll
+                for (int i = 0; i < RV; i++) {
+                    const int32_t diff = wadd(rr[i], tend_apply(top, tp[i]));
+                    o1[i] = wadd(av[i], diff / 2);
+                    o2[i] = wsub(o1[i], diff);
+                    top = o2[i];
+                }
             }
 #pragma unroll
             for (int i = 0; i < RV; i++) {
@@ -194,13 +266,28 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
 #pragma unroll
                     for (int j = 0; j < U; j++) tp[j] = tend_pre(va[j], va[j + 1]);
                     int32_t o1[U], o2[U];
+                    TendFast tf[U];
+#pragma unroll
+                    for (int j = 0; j < U; j++) tf[j] = tend_fast_pre(va[j], va[j + 1]);
+                    const int32_t left0 = (x0 + i0) > 0 ? left : va[0];  // the first pair of a row uses its own average
+                    left = left0;
+                    bool unsafe = false;
 #pragma unroll
                     for (int j = 0; j < U; j++) {
-                        const int32_t l = (x0 + i0 + j) > 0 ? left : va[j];
-                        const int32_t diff = wadd(vr[j], tend_apply(l, tp[j]));
+                        const int32_t diff = wadd(vr[j], tend_fast_apply(left, tf[j], unsafe));
                         o1[j] = wadd(va[j], diff / 2);
                         o2[j] = wsub(o1[j], diff);
                         left = o2[j];
+                    }
+                    if (__builtin_expect(__any(unsafe), 0)) {  // operands near the int32 limits: exact long form
+                        left = left0;
+#pragma unroll
+                        for (int j = 0; j < U; j++) {
+                            const int32_t diff = wadd(vr[j], tend_apply(left, tp[j]));
+                            o1[j] = wadd(va[j], diff / 2);
+                            o2[j] = wsub(o1[j], diff);
+                            left = o2[j];
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < U; j++) {

@@ -364,3 +364,57 @@ def test_cosine_lut_is_exactly_mirror_symmetric(orc):
             mirrored = row[::-1] * (np.float32(-1.0) if n % 2 else np.float32(1.0))
             assert np.array_equal(row.view(np.uint32), mirrored.view(np.uint32)), (s, n)
         assert not (lut == 0).any()  # no signed-zero ambiguity
+
+
+def test_tendency_min_max_form(orc):
+    """the device kernels' short form of ModularChannel.tendency (k_modular.hip, tend_fast_apply): min/max instead of the
+    parity-and-compare clamps. Checked against the oracle's inverse squeeze through 1-pair rows (out[1] = avg + diff/2 - diff
+    exposes tendency(left=avg, avg, next)) -- and directly against a numpy restatement over the safe operand range."""
+    def wrap(x):
+        return ((x + 2**31) % 2**32) - 2**31
+
+    def tdiv(n, d):
+        return np.where(n >= 0, n // d, -((-n) // d))
+
+    def ref(a, b, c):
+        dec = (a >= b) & (b >= c)
+        inc = (~dec) & (a <= b) & (b <= c)
+        d, e = wrap(2 * wrap(a - b)), wrap(2 * wrap(b - c))
+        x = tdiv(wrap(4 * a - 3 * c - b + 6), 12)
+        x = np.where(wrap(x - (x & 1)) > d, wrap(d + 1), x)
+        x = np.where(wrap(x + (x & 1)) > e, e, x)
+        y = tdiv(wrap(4 * a - 3 * c - b - 6), 12)
+        y = np.where(wrap(y + (y & 1)) < d, wrap(d - 1), y)
+        y = np.where(wrap(y - (y & 1)) < e, e, y)
+        return np.where(dec, x, np.where(inc, y, 0))
+
+    def fast(a, b, c):
+        dec = (a >= b) & (b >= c)
+        inc = (~dec) & (a <= b) & (b <= c)
+        d, e = wrap(2 * wrap(a - b)), wrap(2 * wrap(b - c))
+        x = tdiv(wrap(4 * a - 3 * c - b + 6), 12)
+        y = tdiv(wrap(4 * a - 3 * c - b - 6), 12)
+        return np.where(dec, np.minimum(np.minimum(x, wrap(d + 1)), e), np.where(inc, np.maximum(np.maximum(y, wrap(d - 1)), e), 0))
+    g = np.arange(-30, 31, dtype=np.int64)
+    A, B, C = np.meshgrid(g, g, g, indexing="ij")
+    assert np.array_equal(ref(A, B, C), fast(A, B, C))
+    rng = np.random.default_rng(11)
+    for scale in (1 << 10, 1 << 20, 1 << 28):
+        a = rng.integers(-scale, scale, 500_000)
+        b = a + rng.integers(-scale // 4 - 1, scale // 4 + 1, a.size)
+        c = b + rng.integers(-scale // 4 - 1, scale // 4 + 1, a.size)
+        safe = (np.abs(a - b) < 2**29) & (np.abs(b - c) < 2**29)
+        assert np.array_equal(ref(a, b, c)[safe], fast(a, b, c)[safe])
+    # the numpy restatement itself agrees with the oracle: row [avg, next] with residual r gives out[1] = avg + t/2... use
+    # the two-pair row (avg0, avg1), residuals (0, r): second pair has left = out[1] of the first
+    a = rng.integers(-1000, 1000, (2000, 2)).astype(np.int32)
+    r = rng.integers(-50, 50, (2000, 2)).astype(np.int32)
+    out = orc.inv_hsqueeze(a, r)
+    t0 = ref(a[:, 0].astype(np.int64), a[:, 0].astype(np.int64), a[:, 1].astype(np.int64))
+    diff0 = r[:, 0] + t0
+    first0 = a[:, 0] + tdiv(diff0, 2)
+    assert np.array_equal(out[:, 0], first0) and np.array_equal(out[:, 1], first0 - diff0)
+    t1 = ref(out[:, 1].astype(np.int64), a[:, 1].astype(np.int64), a[:, 1].astype(np.int64))
+    diff1 = r[:, 1] + t1
+    first1 = a[:, 1] + tdiv(diff1, 2)
+    assert np.array_equal(out[:, 2], first1) and np.array_equal(out[:, 3], first1 - diff1)
