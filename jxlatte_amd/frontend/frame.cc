@@ -2,6 +2,10 @@
 
 #include <algorithm>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
 
 #include "../../include/jxl_transform_types.h"
 
@@ -622,6 +626,14 @@ void Frame::read_pass_group(BitReader& br, int pass, int group, const std::vecto
 void Frame::decode(BitReader& br, const TransformHooks* hooks) {  // Frame.decodeFrame (:376-461), front part
     const bool single = toc.lengths.size() == 1;
     const size_t base = br.byte_pos();
+    const bool timing = getenv("JXF_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  [jxf] %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (!single && (br.bit_pos() & 7)) throw std::logic_error("TOC must end byte aligned");
     BitReader shared = br;  // single-section frames read everything through one cursor
     auto sec = [&](int logical) -> BitReader { return section(br, base, logical, false); };
@@ -632,6 +644,7 @@ void Frame::decode(BitReader& br, const TransformHooks* hooks) {  // Frame.decod
         BitReader r = sec(0);
         read_lf_global(r);
     }
+    lap("LfGlobal");
     // LF groups
     std::vector<int> lf_replaced;
     for (size_t i = 0; i < global_modular.channels.size(); i++) {
@@ -639,17 +652,29 @@ void Frame::decode(BitReader& br, const TransformHooks* hooks) {  // Frame.decod
         if (!c.decoded && c.vshift >= 3 && c.hshift >= 3) lf_replaced.push_back((int)i);
     }
     lf_groups.assign(num_lf_groups, LFGroupData());
-    for (int g = 0; g < num_lf_groups; g++) {
-        if (single) read_lf_group(shared, g, lf_replaced);
-        else {
-            BitReader r = sec(1 + g);
-            read_lf_group(r, g, lf_replaced);
+    if (single) {
+        for (int g = 0; g < num_lf_groups; g++) read_lf_group(shared, g, lf_replaced);
+    } else {
+        for (int ci : lf_replaced) global_modular.channels[ci].allocate();
+        std::exception_ptr err;
+#pragma omp parallel for schedule(dynamic)
+        for (int g = 0; g < num_lf_groups; g++) {
+            try {
+                BitReader r = sec(1 + g);
+                read_lf_group(r, g, lf_replaced);
+            } catch (...) {
+#pragma omp critical(jxf_err)
+                if (!err) err = std::current_exception();
+            }
         }
+        if (err) std::rethrow_exception(err);
     }
     for (int ci : lf_replaced) global_modular.channels[ci].decoded = true;
+    lap("LF groups");
     // HfGlobal + pass headers
     BitReader hfg = single ? shared : sec(1 + num_lf_groups);
     read_hf_global(single ? shared : hfg);
+    lap("HfGlobal");
     // pass groups
     coeffs.assign(fh.passes.num_passes, std::vector<GroupCoeffs>(fh.encoding == kVarDCT ? num_groups : 0));
     for (int p = 0; p < fh.passes.num_passes; p++) {
@@ -660,17 +685,30 @@ void Frame::decode(BitReader& br, const TransformHooks* hooks) {  // Frame.decod
             const int m = std::min(c.vshift, c.hshift);
             if (pass_min_shift_[p] <= m && m < pass_max_shift_[p]) replaced.push_back((int)i);
         }
-        for (int g = 0; g < num_groups; g++) {
-            if (single) read_pass_group(shared, p, g, replaced);
-            else {
-                BitReader r = sec(2 + num_lf_groups + p * num_groups + g);
-                read_pass_group(r, p, g, replaced);
+        if (single) {
+            for (int g = 0; g < num_groups; g++) read_pass_group(shared, p, g, replaced);
+        } else {
+            // the sections of one pass are independent bitstreams over disjoint regions: decode them on all host cores
+            for (int ci : replaced) global_modular.channels[ci].allocate();
+            std::exception_ptr err;
+#pragma omp parallel for schedule(dynamic)
+            for (int g = 0; g < num_groups; g++) {
+                try {
+                    BitReader r = sec(2 + num_lf_groups + p * num_groups + g);
+                    read_pass_group(r, p, g, replaced);
+                } catch (...) {
+#pragma omp critical(jxf_err)
+                    if (!err) err = std::current_exception();
+                }
             }
+            if (err) std::rethrow_exception(err);
         }
         for (int ci : replaced) global_modular.channels[ci].decoded = true;
     }
+    lap("pass groups");
     for (Channel& c : global_modular.channels) c.allocate();
     global_modular.apply_transforms(hooks);
+    lap("transforms");
     if (single) {
         br = shared;
     } else {
