@@ -21,6 +21,7 @@
 // Frame edges: Gab reads clamped coordinates, EPF reads mirrored ones (MathHelper.mirrorCoordinate);
 // edge tiles re-create that by copying mirrored positions inside LDS after each stage.
 #include "jxl_internal.h"
+#include <cstdlib>
 
 namespace jxl {
 
@@ -76,7 +77,7 @@ __device__ __forceinline__ float adiff(const float* p, int u, int v, float s) {
 // One EPF iteration (Frame.java:583-635) on a 4x2 patch whose top-left sample is (ry, rx) in region
 // coordinates of src (3 planes, stride SW). Results for the 8 pixels go to res[c][py*4+px].
 // ITER: 0 = 13 taps with cross distances, 1 = 5 taps with cross distances, 2 = 5 taps single-pixel.
-template <int ITER, int SW, int PLANE, int PH>
+template <int ITER, int SW, int PLANE, int PH, bool CHAINS = true>
 __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry, int rx, const float* s_inv /*[NP]*/,
                                           const bool* border /*[NP]*/, const EpfParams& ep, float res[3][4 * PH]) {
     constexpr int NP = 4 * PH;  // pixels per patch
@@ -95,6 +96,66 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
 #pragma unroll
         for (int t = 0; t < NT; t++) dist[i][t] = 0.0f;
 
+    if (ITER != 0 && CHAINS) {
+        // The distance of pixel p to its east neighbour IS the distance of p+1 to its west neighbour: the same
+        // terms |P(p+k) - P(p+1+k)| * s in the same channel-major, cross-minor order (likewise south/north). So a
+        // patch needs one chain per horizontally / vertically adjacent pixel PAIR, not one per (pixel, tap):
+        //   hc[py][j] = distance between (py, j-1) and (py, j), j = 0..4;  vc[i][px] = between (i-1, px) and (i, px), i = 0..PH
+        float hc[PH][5], vc[PH + 1][4];
+#pragma unroll
+        for (int py = 0; py < PH; py++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) hc[py][j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i <= PH; i++)
+#pragma unroll
+            for (int px = 0; px < 4; px++) vc[i][px] = 0.0f;
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            float nb[NH * NW];
+            const float* pc = src + c * PLANE + (ry - R) * SW + (rx - R);
+#pragma unroll
+            for (int y = 0; y < NH; y++)
+#pragma unroll
+                for (int x = 0; x < NW; x++) nb[y * NW + x] = pc[y * SW + x];
+            const float sc = ep.channel_scale[c];
+#pragma unroll
+            for (int py = 0; py < PH; py++)
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int cy = py + R, cx = j - 1 + R;
+                    if (ITER == 2) hc[py][j] = hc[py][j] + adiff<NW>(nb, cy * NW + cx, cy * NW + cx + 1, sc);
+                    else
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const int u = (cy + QY[q]) * NW + cx + QX[q];
+                            hc[py][j] = hc[py][j] + adiff<NW>(nb, u, u + 1, sc);
+                        }
+                }
+#pragma unroll
+            for (int i = 0; i <= PH; i++)
+#pragma unroll
+                for (int px = 0; px < 4; px++) {
+                    const int cy = i - 1 + R, cx = px + R;
+                    if (ITER == 2) vc[i][px] = vc[i][px] + adiff<NW>(nb, cy * NW + cx, (cy + 1) * NW + cx, sc);
+                    else
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            const int u = (cy + QY[q]) * NW + cx + QX[q];
+                            vc[i][px] = vc[i][px] + adiff<NW>(nb, u, u + NW, sc);
+                        }
+                }
+        }
+#pragma unroll
+        for (int py = 0; py < PH; py++)
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                dist[py * 4 + px][0] = hc[py][px];      // tap (0,-1)
+                dist[py * 4 + px][1] = hc[py][px + 1];  // tap (0,+1)
+                dist[py * 4 + px][2] = vc[py][px];      // tap (-1,0)
+                dist[py * 4 + px][3] = vc[py + 1][px];  // tap (+1,0)
+            }
+    } else {
     // channels one after the other (not interleaved by the scheduler): keeps the live set under 128 VGPRs
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {
@@ -127,6 +188,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                     }
                 }
             }
+    }
     }
     // weights (epfWeight, :671-679), in place of the distances
     float sumW[NP];
@@ -252,6 +314,9 @@ struct FusedArgs {
 };
 
 typedef float v2f_t __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) f2a4 {
+    float x, y;
+};
 struct __attribute__((packed, aligned(8))) f4a8 {
     float x, y, z, w;
 };
@@ -381,7 +446,30 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
     }
     // load the input tile: clamped coordinates feed Gab, mirrored ones feed EPF directly. Flat row-major
     // walk with incrementally updated (y, x) and 32-bit plane offsets (scalar base + 32-bit lane offset).
-    {
+    if (!tc.edge) {
+        // interior tile: no coordinate fix-ups; two samples per lane and load (the tile origin is only 4-byte aligned)
+        static_assert(G::IW % 2 == 0, "pairs");
+        constexpr int PAIRS = G::IW / 2, TOTAL = PAIRS * G::IH;
+        const uint32_t base = (uint32_t)(tc.iy0 * W + tc.ix0);
+#pragma unroll
+        for (int k = 0; k < (TOTAL + NTHR - 1) / NTHR; k++) {
+            const int idx = (int)threadIdx.x + k * NTHR;
+            if (idx < TOTAL) {
+                const int y = idx / PAIRS, x = (idx - y * PAIRS) * 2;
+                const uint32_t g = base + (uint32_t)(y * W + x);
+                const f2a4 v0 = *reinterpret_cast<const f2a4*>(a.in[0] + g);
+                const f2a4 v1 = *reinterpret_cast<const f2a4*>(a.in[1] + g);
+                const f2a4 v2 = *reinterpret_cast<const f2a4*>(a.in[2] + g);
+                float* d = A + y * G::SW + x;
+                d[0] = v0.x;
+                d[1] = v0.y;
+                d[G::PLANE] = v1.x;
+                d[G::PLANE + 1] = v1.y;
+                d[2 * G::PLANE] = v2.x;
+                d[2 * G::PLANE + 1] = v2.y;
+            }
+        }
+    } else {
         constexpr int STEP_Y = NTHR / G::IW, STEP_X = NTHR % G::IW;
         int y = threadIdx.x / G::IW, x = threadIdx.x % G::IW;
         const float* __restrict__ in0 = a.in[0];
@@ -389,14 +477,12 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
         const float* __restrict__ in2 = a.in[2];
         while (y < G::IH) {
             int gy = tc.iy0 + y, gx = tc.ix0 + x;
-            if (tc.edge) {
-                if (GAB) {
-                    gy = min(max(gy, 0), H - 1);
-                    gx = min(max(gx, 0), W - 1);
-                } else {
-                    gy = mirror_c(gy, H);
-                    gx = mirror_c(gx, W);
-                }
+            if (GAB) {
+                gy = min(max(gy, 0), H - 1);
+                gx = min(max(gx, 0), W - 1);
+            } else {
+                gy = mirror_c(gy, H);
+                gx = mirror_c(gx, W);
             }
             const uint32_t g = (uint32_t)(gy * W + gx);
             const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
@@ -416,25 +502,40 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
     float* cur = A;
     float* oth = B;
     int m = 0;
-    if (GAB) {  // Frame.performGabConvolution (:505-542): lane = pixel (consecutive lanes = consecutive x: conflict-free
-                // LDS rows, perfectly balanced; a 4x1 register-patch form measured 6% slower on the whole kernel)
+    if (GAB) {  // Frame.performGabConvolution (:505-542). Lane = column (consecutive lanes = consecutive x: conflict-free
+                // LDS rows), walking down a segment of rows with the 3x3 neighbourhood sliding through registers: three
+                // new samples and 10 flops per output. (W + E) of a row is the first partial sum of both its own `adj`
+                // and of the `diag` of the row below -- same operands, same order -- so it is formed once.
         m = 1;
         constexpr int rw = G::IW - 2, rh = G::IH - 2;
-        constexpr int STEP_Y = NTHR / rw, STEP_X = NTHR % rw;
-        int y = threadIdx.x / rw, x = threadIdx.x % rw;
-        while (y < rh) {
+        constexpr int NCOLSEG = NTHR / rw;                         // row segments worked on at once
+        constexpr int SEG = (rh + NCOLSEG - 1) / NCOLSEG;          // rows per segment
+        constexpr int NSEG = (rh + SEG - 1) / SEG;
+        static_assert(NSEG * rw <= NTHR, "one pass");
+        const int seg = threadIdx.x / rw, x = threadIdx.x - seg * rw;
+        if (seg < NSEG) {
+            const int y0 = seg * SEG;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float* p = cur + c * G::PLANE + (y + 1) * G::SW + x + 1;
-                const float adj = p[-1] + p[1] + p[-G::SW] + p[G::SW];
-                const float diag = p[-G::SW - 1] + p[-G::SW + 1] + p[G::SW - 1] + p[G::SW + 1];
-                oth[c * G::PLANE + (y + 1) * G::SW + x + 1] = a.p.gab_base[c] * p[0] + a.p.gab_adj[c] * adj + a.p.gab_diag[c] * diag;
-            }
-            x += STEP_X;
-            y += STEP_Y;
-            if (x >= rw) {
-                x -= rw;
-                y++;
+                const float* p = cur + c * G::PLANE + y0 * G::SW + x;
+                float* o = oth + c * G::PLANE + (y0 + 1) * G::SW + x + 1;
+                float a0 = p[0], a1 = p[1], a2 = p[2];
+                float b0 = p[G::SW], b1 = p[G::SW + 1], b2 = p[G::SW + 2];
+                float hs_a = a0 + a2;
+                const float wb = a.p.gab_base[c], wa = a.p.gab_adj[c], wd = a.p.gab_diag[c];
+#pragma unroll
+                for (int k = 0; k < SEG; k++) {
+                    if (y0 + k < rh) {
+                        const float c0 = p[(k + 2) * G::SW], c1 = p[(k + 2) * G::SW + 1], c2 = p[(k + 2) * G::SW + 2];
+                        const float hs_b = b0 + b2;
+                        const float adj = hs_b + a1 + c1;    // p[-1] + p[1] + p[-SW] + p[SW]
+                        const float diag = hs_a + c0 + c2;   // p[-SW-1] + p[-SW+1] + p[SW-1] + p[SW+1]
+                        o[k * G::SW] = wb * b1 + wa * adj + wd * diag;
+                        a1 = b1;
+                        hs_a = hs_b;
+                        b0 = c0; b1 = c1; b2 = c2;
+                    }
+                }
             }
         }
         if (tc.edge && ITERS > 0) mirror_fixup<G, NTHR>(oth, m, G::RE, tc);
@@ -473,12 +574,9 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
     }
 }
 
-template <bool GAB, int ITERS, bool PLAIN>
-void launch_tp(const FusedArgs& a, hipStream_t s) {
+template <bool GAB, int ITERS, bool PLAIN, int PH>
+void launch_tph(const FusedArgs& a, hipStream_t s) {
     using G = Geo<GAB, ITERS>;
-    // iteration 0 (13 taps) keeps the 4x2 patch / 256 threads; the common configurations run 4x1 patches on
-    // 512 threads: twice the waves per CU for the same LDS footprint
-    constexpr int PH = ITERS == 3 ? 2 : 1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused<GAB, ITERS, PLAIN, PH>),
@@ -488,6 +586,14 @@ void launch_tp(const FusedArgs& a, hipStream_t s) {
     const int n_tiles = ((a.W + G::OW - 1) / G::OW) * ((a.H + G::OH - 1) / G::OH);
     const dim3 grid(((n_tiles + 7) / 8) * 8);
     hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES, s, a);
+}
+template <bool GAB, int ITERS, bool PLAIN>
+void launch_tp(const FusedArgs& a, hipStream_t s) {
+    // iteration 0 (13 taps) keeps the 4x2 patch / 256 threads; the common configurations run 4x1 patches on
+    // 512 threads: twice the waves per CU for the same LDS footprint
+    static const int ph_env = getenv("JXL_RESTORE_PH") ? atoi(getenv("JXL_RESTORE_PH")) : 0;
+    if (ITERS == 3 || ph_env == 2) launch_tph<GAB, ITERS, PLAIN, 2>(a, s);
+    else launch_tph<GAB, ITERS, PLAIN, 1>(a, s);
 }
 
 template <bool GAB, int ITERS>
