@@ -79,7 +79,7 @@ __device__ __forceinline__ float adiff(const float* p, int u, int v, float s) {
 // ITER: 0 = 13 taps with cross distances, 1 = 5 taps with cross distances, 2 = 5 taps single-pixel.
 template <int ITER, int SW, int PLANE, int PH, bool CHAINS = true>
 __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry, int rx, const float* s_inv /*[NP]*/,
-                                          const bool* border /*[NP]*/, const EpfParams& ep, float res[3][4 * PH]) {
+                                          const float* bmul /*[NP]*/, const EpfParams& ep, float res[3][4 * PH]) {
     constexpr int NP = 4 * PH;  // pixels per patch
     constexpr int R = ITER == 0 ? 3 : ITER == 1 ? 2 : 1;  // neighbourhood radius
     constexpr int NW = 4 + 2 * R, NH = PH + 2 * R;
@@ -200,8 +200,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
         float sw = 0.0f + 1.0f;                     // centre tap: dist 0 -> weight 1 (finite samples)
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            float d = dist[i][t];
-            if (border[i]) d = d * ep.border_sad_mul;
+            const float d = dist[i][t] * bmul[i];
             const float v = 1.0f - d * ep.sigma_scale * s;
             const float w = v < 0.0f ? 0.0f : v;
             dist[i][t] = w;
@@ -251,20 +250,26 @@ __device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* 
     for (int pi = threadIdx.x; pi < pcols * prows; pi += NTHR) {
         const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
         float s_inv[4 * PH];
-        bool border[4 * PH];
+        float bmul[4 * PH];  // epfWeight's border factor (:672-675): border_sad_mul on 8x8-border rows/columns, else 1 (d * 1 == d)
+        const int gx0 = tc.ix0 + rx;
+        // a 4-pixel run touches at most two cells: look up the first and the last, pick per pixel. Out-of-frame
+        // positions (only on edge tiles) get some in-range cell; they are recomputed by the mirror fix-up.
+        const int cxa = (min(max(gx0, 0), tc.W - 1) >> 3) - scx0, cxb = (min(max(gx0 + 3, 0), tc.W - 1) >> 3) - scx0;
 #pragma unroll
-        for (int py = 0; py < PH; py++)
+        for (int py = 0; py < PH; py++) {
+            const int gy = tc.iy0 + ry + py;
+            const bool rowb = ((gy + 1) & 7) < 2;  // gy & 7 is 7 or 0
+            const int crow = ((min(max(gy, 0), tc.H - 1) >> 3) - scy0) * 16;
+            const float sa = sig[crow + cxa], sb = sig[crow + cxb];
 #pragma unroll
             for (int px = 0; px < 4; px++) {
-                int gy = tc.iy0 + ry + py, gx = tc.ix0 + rx + px;
-                const int modY = gy & 7, modX = gx & 7;
-                border[py * 4 + px] = modY == 0 || modY == 7 || modX == 0 || modX == 7;
-                gy = min(max(gy, 0), tc.H - 1);  // out-of-frame positions are recomputed by the mirror fix-up
-                gx = min(max(gx, 0), tc.W - 1);
-                s_inv[py * 4 + px] = sig[((gy >> 3) - scy0) * 16 + ((gx >> 3) - scx0)];
+                const int gx = gx0 + px;
+                bmul[py * 4 + px] = (rowb || ((gx + 1) & 7) < 2) ? ep.border_sad_mul : 1.0f;
+                s_inv[py * 4 + px] = (gx >> 3) == (gx0 >> 3) ? sa : sb;
             }
+        }
         float res[3][4 * PH];
-        epf_patch<ITER, SW, PLANE, PH>(src, ry, rx, s_inv, border, ep, res);
+        epf_patch<ITER, SW, PLANE, PH>(src, ry, rx, s_inv, bmul, ep, res);
 #pragma unroll
         for (int py = 0; py < PH; py++) {
             const int y = ry + py;
