@@ -49,7 +49,7 @@ struct Geo {
     static constexpr int SW = IW + 3;                                         // LDS row stride (patch over-read <= 3)
     static constexpr int SH = IH + 1;
     static constexpr int PLANE = SW * SH;
-    static constexpr size_t LDS_BYTES = sizeof(float) * (2 * 3 * PLANE + 16 * 16);
+    static constexpr size_t LDS_BYTES = sizeof(float) * (3 * PLANE + 16 * 16);
 };
 
 // Java (int)float
@@ -239,49 +239,77 @@ struct TileCtx {
     bool edge;
 };
 
-// run one EPF iteration over the output region [m, IH-m) x [m, IW-m) of the tile
+// s_inv / border factor of the 4 x PH pixels of a patch
+template <int PH>
+__device__ __forceinline__ void patch_sigma(int ry, int rx, const TileCtx& tc, const float* __restrict__ sig, int scy0, int scx0,
+                                            const EpfParams& ep, float s_inv[4 * PH], float bmul[4 * PH]) {
+    const int gx0 = tc.ix0 + rx;
+    // a 4-pixel run touches at most two cells: look up the first and the last, pick per pixel. Out-of-frame
+    // positions (only on edge tiles) get some in-range cell; they are recomputed by the mirror fix-up.
+    const int cxa = (min(max(gx0, 0), tc.W - 1) >> 3) - scx0, cxb = (min(max(gx0 + 3, 0), tc.W - 1) >> 3) - scx0;
+#pragma unroll
+    for (int py = 0; py < PH; py++) {
+        const int gy = tc.iy0 + ry + py;
+        const bool rowb = ((gy + 1) & 7) < 2;  // gy & 7 is 7 or 0
+        const int crow = ((min(max(gy, 0), tc.H - 1) >> 3) - scy0) * 16;
+        const float sa = sig[crow + cxa], sb = sig[crow + cxb];
+#pragma unroll
+        for (int px = 0; px < 4; px++) {
+            const int gx = gx0 + px;
+            // epfWeight's border factor (:672-675): border_sad_mul on 8x8-border rows/columns, else 1 (d * 1 == d)
+            bmul[py * 4 + px] = (rowb || ((gx + 1) & 7) < 2) ? ep.border_sad_mul : 1.0f;
+            s_inv[py * 4 + px] = (gx >> 3) == (gx0 >> 3) ? sa : sb;
+        }
+    }
+}
+
+// run one EPF iteration over the output region [m, IH-m) x [m, IW-m) of the tile.
+// LAST: results go to the sink (colour + global store). Otherwise IN PLACE: every thread computes the one patch it owns
+// into registers, the workgroup meets at a barrier (all reads of the old values done), then the patches are written
+// back over the input. One LDS buffer instead of two doubles the workgroups a CU can hold.
 template <int ITER, typename G, bool LAST, int PH, typename Sink>
-__device__ __forceinline__ void epf_stage(const float* __restrict__ src, float* __restrict__ dst, int m, const TileCtx& tc,
-                                          const float* __restrict__ sig, int scy0, int scx0, const EpfParams& ep, Sink sink) {
+__device__ __forceinline__ void epf_stage(float* buf, int m, const TileCtx& tc, const float* __restrict__ sig, int scy0, int scx0,
+                                          const EpfParams& ep, Sink sink) {
     constexpr int SW = G::SW, PLANE = G::PLANE;
     const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
     constexpr int NTHR = 512 / PH;
     const int pcols = (rw + 3) >> 2, prows = (rh + PH - 1) / PH;
-    for (int pi = threadIdx.x; pi < pcols * prows; pi += NTHR) {
-        const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
-        float s_inv[4 * PH];
-        float bmul[4 * PH];  // epfWeight's border factor (:672-675): border_sad_mul on 8x8-border rows/columns, else 1 (d * 1 == d)
-        const int gx0 = tc.ix0 + rx;
-        // a 4-pixel run touches at most two cells: look up the first and the last, pick per pixel. Out-of-frame
-        // positions (only on edge tiles) get some in-range cell; they are recomputed by the mirror fix-up.
-        const int cxa = (min(max(gx0, 0), tc.W - 1) >> 3) - scx0, cxb = (min(max(gx0 + 3, 0), tc.W - 1) >> 3) - scx0;
+    if (LAST) {
+        for (int pi = threadIdx.x; pi < pcols * prows; pi += NTHR) {
+            const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
+            float s_inv[4 * PH], bmul[4 * PH];
+            patch_sigma<PH>(ry, rx, tc, sig, scy0, scx0, ep, s_inv, bmul);
+            float res[3][4 * PH];
+            epf_patch<ITER, SW, PLANE, PH>(buf, ry, rx, s_inv, bmul, ep, res);
 #pragma unroll
-        for (int py = 0; py < PH; py++) {
-            const int gy = tc.iy0 + ry + py;
-            const bool rowb = ((gy + 1) & 7) < 2;  // gy & 7 is 7 or 0
-            const int crow = ((min(max(gy, 0), tc.H - 1) >> 3) - scy0) * 16;
-            const float sa = sig[crow + cxa], sb = sig[crow + cxb];
-#pragma unroll
-            for (int px = 0; px < 4; px++) {
-                const int gx = gx0 + px;
-                bmul[py * 4 + px] = (rowb || ((gx + 1) & 7) < 2) ? ep.border_sad_mul : 1.0f;
-                s_inv[py * 4 + px] = (gx >> 3) == (gx0 >> 3) ? sa : sb;
+            for (int py = 0; py < PH; py++) {
+                const int y = ry + py;
+                if (y < G::IH - m) sink.row4(y, rx, &res[0][py * 4], &res[1][py * 4], &res[2][py * 4], min(4, G::IW - m - rx));
             }
         }
+    } else {
+        // the largest region any stage sees is the 64x32 window: one patch per thread
+        static_assert((64 / 4) * ((32 + PH - 1) / PH) <= NTHR, "one patch per thread");
+        const int pi = threadIdx.x;
+        const bool act = pi < pcols * prows;
+        const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
         float res[3][4 * PH];
-        epf_patch<ITER, SW, PLANE, PH>(src, ry, rx, s_inv, bmul, ep, res);
+        if (act) {
+            float s_inv[4 * PH], bmul[4 * PH];
+            patch_sigma<PH>(ry, rx, tc, sig, scy0, scx0, ep, s_inv, bmul);
+            epf_patch<ITER, SW, PLANE, PH>(buf, ry, rx, s_inv, bmul, ep, res);
+        }
+        __syncthreads();
+        if (act) {
 #pragma unroll
-        for (int py = 0; py < PH; py++) {
-            const int y = ry + py;
-            if (LAST) {
-                if (y < G::IH - m) sink.row4(y, rx, &res[0][py * 4], &res[1][py * 4], &res[2][py * 4], min(4, G::IW - m - rx));
-            } else {
+            for (int py = 0; py < PH; py++) {
+                const int y = ry + py;
 #pragma unroll
                 for (int px = 0; px < 4; px++) {
                     const int x = rx + px;
                     if (y < G::IH - m && x < G::IW - m) {
 #pragma unroll
-                        for (int c = 0; c < 3; c++) dst[c * PLANE + y * SW + x] = res[c][py * 4 + px];
+                        for (int c = 0; c < 3; c++) buf[c * PLANE + y * SW + x] = res[c][py * 4 + px];
                     }
                 }
             }
@@ -413,13 +441,12 @@ struct OutSink {
 // PLAIN = true: float planes out, no transfer function (keeps the double-precision pow() code of the
 // PQ/sRGB transfer out of the hot variant)
 template <bool GAB, int ITERS, bool PLAIN, int PH>
-__global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(const FusedArgs a) {
+__global__ __launch_bounds__(512 / PH, PH == 1 ? 8 : 4) void k_restore_fused(const FusedArgs a) {
     using G = Geo<GAB, ITERS>;
     constexpr int NTHR = 512 / PH;
     extern __shared__ float lds[];
-    float* A = lds;
-    float* B = lds + 3 * G::PLANE;
-    float* sig = lds + 6 * G::PLANE;  // [16][16] inverse sigma of the cells under the tile
+    float* A = lds;                   // the tile: 3 planes, every stage works in place
+    float* sig = lds + 3 * G::PLANE;  // [16][16] inverse sigma of the cells under the tile
     const int W = a.W, H = a.H;
     TileCtx tc;
     tc.W = W;
@@ -505,7 +532,6 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
     }
     __syncthreads();
     float* cur = A;
-    float* oth = B;
     int m = 0;
     if (GAB) {  // Frame.performGabConvolution (:505-542). Lane = column (consecutive lanes = consecutive x: conflict-free
                 // LDS rows), walking down a segment of rows with the 3x3 neighbourhood sliding through registers: three
@@ -518,12 +544,12 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
         constexpr int NSEG = (rh + SEG - 1) / SEG;
         static_assert(NSEG * rw <= NTHR, "one pass");
         const int seg = threadIdx.x / rw, x = threadIdx.x - seg * rw;
+        const int y0 = seg * SEG;
+        float go[3][SEG];
         if (seg < NSEG) {
-            const int y0 = seg * SEG;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const float* p = cur + c * G::PLANE + y0 * G::SW + x;
-                float* o = oth + c * G::PLANE + (y0 + 1) * G::SW + x + 1;
                 float a0 = p[0], a1 = p[1], a2 = p[2];
                 float b0 = p[G::SW], b1 = p[G::SW + 1], b2 = p[G::SW + 2];
                 float hs_a = a0 + a2;
@@ -535,7 +561,7 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
                         const float hs_b = b0 + b2;
                         const float adj = hs_b + a1 + c1;    // p[-1] + p[1] + p[-SW] + p[SW]
                         const float diag = hs_a + c0 + c2;   // p[-SW-1] + p[-SW+1] + p[SW-1] + p[SW+1]
-                        o[k * G::SW] = wb * b1 + wa * adj + wd * diag;
+                        go[c][k] = wb * b1 + wa * adj + wd * diag;
                         a1 = b1;
                         hs_a = hs_b;
                         b0 = c0; b1 = c1; b2 = c2;
@@ -543,9 +569,18 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
                 }
             }
         }
-        if (tc.edge && ITERS > 0) mirror_fixup<G, NTHR>(oth, m, G::RE, tc);
+        __syncthreads();  // every read of the un-filtered tile is done: write the results over it
+        if (seg < NSEG) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float* o = cur + c * G::PLANE + (y0 + 1) * G::SW + x + 1;
+#pragma unroll
+                for (int k = 0; k < SEG; k++)
+                    if (y0 + k < rh) o[k * G::SW] = go[c][k];
+            }
+        }
+        if (tc.edge && ITERS > 0) mirror_fixup<G, NTHR>(cur, m, G::RE, tc);
         __syncthreads();
-        float* t = cur; cur = oth; oth = t;
     }
 
     // final sink: XYB + transfer/quantise + global store
@@ -561,21 +596,19 @@ __global__ __launch_bounds__(512 / PH, PH == 1 ? 4 : 2) void k_restore_fused(con
     }
     if (ITERS == 3) {
         m += 3;
-        epf_stage<0, G, false, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
-        if (tc.edge) mirror_fixup<G, NTHR>(oth, m, G::R1 + G::R2, tc);
+        epf_stage<0, G, false, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
+        if (tc.edge) mirror_fixup<G, NTHR>(cur, m, G::R1 + G::R2, tc);
         __syncthreads();
-        float* t = cur; cur = oth; oth = t;
     }
     m += 2;
     if (ITERS >= 2) {
-        epf_stage<1, G, false, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
-        if (tc.edge) mirror_fixup<G, NTHR>(oth, m, G::R2, tc);
+        epf_stage<1, G, false, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
+        if (tc.edge) mirror_fixup<G, NTHR>(cur, m, G::R2, tc);
         __syncthreads();
-        float* t = cur; cur = oth; oth = t;
         m += 1;
-        epf_stage<2, G, true, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[2], sink);
+        epf_stage<2, G, true, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[2], sink);
     } else {
-        epf_stage<1, G, true, PH>(cur, oth, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
+        epf_stage<1, G, true, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
     }
 }
 
