@@ -9,7 +9,7 @@ import os
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libjxlatte_amd.so")
+SO_PATH = os.environ.get("JXL_AMD_LIB") or os.path.join(HERE, "libjxlatte_amd.so")  # override: A/B runs of two builds
 
 
 class LibraryMissing(RuntimeError):

@@ -83,7 +83,8 @@ struct jxl_ctx {
     std::vector<LfJob> lf_jobs;  // integer LF images to dequantise + smooth on the device (row f1)
     DevBuf lfq_tmp[3];
     // binned work
-    struct TypeLaunch { int type, items_off, n_items, channel; };  // channel >= 0: chroma-subsampled frame, one channel per launch
+    // one merged launch: the segments (types) of one register class; channel >= 0: chroma-subsampled frame, one channel per launch
+    struct TypeLaunch { int cls, channel; std::vector<IdctSegment> segs; };
     bool sub = false;      // any jpeg_upsampling shift non-zero
     int sy[3] = {0, 0, 0}, sx[3] = {0, 0, 0};
     DevBuf hfm_sub[3];     // hfMultiplier resampled onto each channel's cell grid
@@ -207,6 +208,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
                     else if (stamp[(size_t)ty * c->tw + tx] != g) mask |= 1u << ((ty - ty0) * 5 + (tx - tx0));
                 }
             b.cfl_zero = mask;
+            b.hf_mul = c->h_hf_mul[(size_t)b.cy * c->bw + b.cx];
             sm[b.type].push_back(b);
         }
     }
@@ -229,16 +231,15 @@ jxl_status finalize_tables(jxl_ctx* c) {
                 c->h_blocks.insert(c->h_blocks.end(), lists[t].begin(), lists[t].end());
             }
         const uint32_t ch0 = channel < 0 ? 0 : (uint32_t)channel, ch1 = channel < 0 ? 3 : (uint32_t)channel + 1;
+        jxl_ctx::TypeLaunch cl[3] = {{1, channel, {}}, {2, channel, {}}, {0, channel, {}}};  // launch order: heaviest class first
         for (int t : kOrder) {
             if (lists[t].empty()) continue;
-            jxl_ctx::TypeLaunch tl{t, (int)items.size(), 0, channel};
-            const uint32_t nb = (uint32_t)medium_blocks_per_wg(t);
-            for (uint32_t o = 0; o < lists[t].size(); o += nb)
-                for (uint32_t ch = ch0; ch < ch1; ch++)
-                    items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(nb, lists[t].size() - o)});
-            tl.n_items = (int)items.size() - tl.items_off;
-            c->type_launches.push_back(tl);
+            const IdctSegment sg{t, (int)first_of[t], (int)lists[t].size()};
+            for (auto& l : cl)
+                if (l.cls == idct_class_of(t)) l.segs.push_back(sg);
         }
+        for (auto& l : cl)
+            if (!l.segs.empty()) c->type_launches.push_back(std::move(l));
         jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel};
         for (int t : kSpecial)
             for (uint32_t o = 0; o < lists[t].size(); o += 64)
@@ -264,7 +265,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
                     if ((cy2 << sy) != b.cy || (cx2 << sx) != b.cx) continue;  // subsampled away
                     if (cy2 * 8 + JXL_TT[t].ph > (c->H >> sy) || cx2 * 8 + JXL_TT[t].pw > (c->W >> sx))
                         return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock (%d,%d) leaves the subsampled channel %d", b.cy, b.cx, ch);
-                    sub_lists[t].push_back(DevBlock{(uint16_t)cy2, (uint16_t)cx2, b.type, 0u});
+                    sub_lists[t].push_back(DevBlock{(uint16_t)cy2, (uint16_t)cx2, b.type, 0u, b.hf_mul});
                     h_hfm_sub[ch][(size_t)cy2 * bwc + cx2] = c->h_hf_mul[(size_t)b.cy * c->bw + b.cx];
                 }
             lay_out(sub_lists, ch);
@@ -639,7 +640,7 @@ jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
         if (by < 0 || bx < 0 || by >= eh || bx >= ew) return fail(c, JXL_ERR_INVALID_BITSTREAM, "block %d at (%d,%d) outside its LF group", i, by, bx);
         const int t = g->dct_select[(size_t)by * ew + bx];
         if (t > 26) return fail(c, JXL_ERR_INVALID_BITSTREAM, "Invalid Transform Type: %d", t);  // HFMetadata.java:46-47
-        bl.push_back(DevBlock{(uint16_t)(y0 + by), (uint16_t)(x0 + bx), (uint32_t)t, 0u});
+        bl.push_back(DevBlock{(uint16_t)(y0 + by), (uint16_t)(x0 + bx), (uint32_t)t, 0u, 1});
     }
     c->lfg_set[g->lfg_y * lrs + g->lfg_x] = 1;
     c->tables_dirty = true;
@@ -784,7 +785,7 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
         int k = 0;
         auto pick = [&]() { const int i = k++; return (!fork || i % (used + 1) == 0) ? s : c->aux[i % (used + 1) - 1]; };
         for (const auto& tl : c->type_launches) {
-            launch_idct_type(frame_of(tl.channel), blocks, items + tl.items_off, tl.n_items, tl.type, A, pick());
+            launch_idct_multi(frame_of(tl.channel), blocks, tl.cls, tl.segs.data(), (int)tl.segs.size(), tl.channel < 0 ? 3 : 1, tl.channel < 0 ? 0 : tl.channel, A, pick());
             launches++;
         }
         for (const auto& sl : c->special_launches) {

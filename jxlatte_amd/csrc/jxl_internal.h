@@ -13,14 +13,19 @@ namespace jxl {
 // total floats of the cosine LUT for sizes 1..256: sum (s-1)*s
 constexpr int kLutTotal = 86870;
 
-// One varblock, frame coordinates. 12 bytes.
+// One varblock, frame coordinates. 16 bytes (one dwordx4 load).
 struct DevBlock {
     uint16_t cy, cx;    // top-left cell (8x8 px units) in the frame
     uint32_t type;      // TransformType.type
     uint32_t cfl_zero;  // bit (ty*5+tx): CfL factors of that 64x64 tile (relative to the block's first
                         // tile) read as 0 for this block -- the reference's per-group xFactors cache has
                         // not been filled yet when this block is visited (HFCoefficients.java:159-181)
+    int32_t hf_mul;     // HFMetadata.hfMultiplier of the block's first cell: carried here so that the kernels do not
+                        // chain a second dependent load behind the block record
 };
+
+// One workgroup's share of a type-uniform launch.
+static_assert(sizeof(DevBlock) == 16, "one dwordx4 per block record");
 
 // One workgroup's share of a type-uniform launch.
 struct WorkItem {
@@ -74,11 +79,31 @@ struct XybParams {
     float cob[3];        // -cbrtOpsinBias
 };
 
+// Argument block of a merged IDCT launch (k_idct_multi): a few type-uniform segments of work items, in launch order.
+struct MultiArgs {
+    static constexpr int kMaxSeg = 12;
+    DevFrame f;
+    const DevBlock* blocks;
+    const WorkItem* items;
+    int n_seg;
+    int seg_b0[kMaxSeg + 1];  // first workgroup of segment k (a multiple of 8); seg_b0[n_seg] = grid size
+    int seg_n[kMaxSeg];       // items in segment k
+    int seg_type[kMaxSeg];    // TransformType.type of segment k
+    int seg_first[kMaxSeg];   // first block of the type in `blocks`
+    int seg_nblocks[kMaxSeg]; // blocks of the type
+    int nch, ch0;             // channels per block group (3, or 1 for a chroma-subsampled frame's per-channel launch), first one
+    float *o0, *o1, *o2;
+};
+// work items are implicit: item i of a segment = channel ch0 + i % nch of block group i / nch, a group being
+// medium_blocks_per_wg(type) consecutive blocks (no item table to load before the block records)
+struct IdctSegment { int type, first_block, n_blocks; };
+
 // ---- launchers (defined in the kernel TUs) ---------------------------------------------------
-// One launch per transform type present (256-thread workgroups). WorkItem.type = TransformType.type | channel << 8;
-// an item covers up to medium_blocks_per_wg(type) blocks of that channel.
-void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, int type, float* const out[3],
-                      hipStream_t s);
+// One launch per register class (0: every type up to 32x32, 1: the 64-point family), 256-thread workgroups.
+// WorkItem.type = TransformType.type | channel << 8; an item covers up to medium_blocks_per_wg(type) blocks of that channel.
+int idct_class_of(int type);
+void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const IdctSegment* segs, int n_seg, int nch, int ch0,
+                       float* const out[3], hipStream_t s);
 // the special 8x8-footprint types: items of up to 64 blocks (one per lane)
 void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],
                          hipStream_t s);

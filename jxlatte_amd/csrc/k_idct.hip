@@ -35,6 +35,27 @@ namespace jxl {
 #include "lut_small.inc"
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Read-only tables (the cosine LUT) are addressed through the constant address space: loads from it are invariant by
+// definition, so a wave-uniform address always becomes a scalar load (s_load_dwordx8 feeding v_pk_mul straight from
+// SGPRs). With plain global pointers the compiler has to prove that no store can clobber the table; in the merged
+// kernels that proof runs out of budget after the first body and the LUT rows arrive as per-lane vector loads instead
+// (measured: 64x64 body 173 -> 330 us).
+typedef const __attribute__((address_space(4))) float* cfloatp;
+typedef const __attribute__((address_space(4))) v2f* cv2fp;
+__device__ __forceinline__ cfloatp as_const(const float* p) { return (cfloatp)p; }
+// one block record (16 bytes, 16-byte aligned) through the constant address space: s_load_dwordx4 when the index is
+// wave-uniform, global_load_dwordx4 when it is per lane
+__device__ __forceinline__ DevBlock load_block(const DevBlock* blocks, int i) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i r = ((const __attribute__((address_space(4))) v4i*)blocks)[i];
+    DevBlock b;
+    b.cy = (uint16_t)((uint32_t)r.x & 0xffffu);
+    b.cx = (uint16_t)((uint32_t)r.x >> 16);
+    b.type = (uint32_t)r.y;
+    b.cfl_zero = (uint32_t)r.z;
+    b.hf_mul = r.w;
+    return b;
+}
 
 static constexpr float kAfv[16][16] = JXL_AFV_BASIS_INIT;
 __constant__ float kLlfScale[32] = JXL_LLF_SCALE_INIT;
@@ -76,9 +97,9 @@ struct MirrorAcc {
     }
     // lut_lo: the first L/2 entries of table row n-1 (or the lane's slice of them)
     template <bool ODD>
-    __device__ __forceinline__ void step(float s, const float* lut_lo) {
+    __device__ __forceinline__ void step(float s, cfloatp lut_lo) {
         const v2f s2 = {s, s};
-        const v2f* lr = reinterpret_cast<const v2f*>(lut_lo);
+        const cv2fp lr = (cv2fp)lut_lo;
 #pragma unroll
         for (int j = 0; j < L / 4; j++) {
             const v2f p = s2 * lr[j];
@@ -341,7 +362,7 @@ __device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock 
     const int W = f.width;
     const int py0 = b.cy * 8, px0 = b.cx * 8;
     const int64_t base = (int64_t)py0 * W + px0;
-    const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+    const float hfm = (float)b.hf_mul;
     float kX, kB;
     cfl_factors(f, py0 >> 6, px0 >> 6, b.cfl_zero & 1u, kX, kB);
     {
@@ -391,7 +412,7 @@ __device__ __forceinline__ void make_block_ctx(const DevFrame& f, const DevBlock
     k.ty0 = k.py0 >> 6;
     k.tx0 = k.px0 >> 6;
     k.cfl_zero = b.cfl_zero;
-    const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+    const float hfm = (float)b.hf_mul;
     for (int c = 0; c < 3; c++) {
         k.sfc[c] = f.scale_factor[c] / hfm;
         k.w[c] = f.weights + f.woffs[PI * 3 + c];
@@ -496,8 +517,8 @@ __device__ __forceinline__ void llf_block(const DevFrame& f, int cy, int cx, int
 template <int DSH, int DSW>
 __device__ __forceinline__ float llf_coeff(const DevFrame& f, const float* __restrict__ lfp /* patch origin, stride f.bw */, int ky,
                                            int kx) {
-    const float* lutw = f.lut + lut_off(ceil_log2_dev(DSW));
-    const float* luth = f.lut + lut_off(ceil_log2_dev(DSH));
+    const cfloatp lutw = as_const(f.lut + lut_off(ceil_log2_dev(DSW)));
+    const cfloatp luth = as_const(f.lut + lut_off(ceil_log2_dev(DSH)));
     const float invw = 1.0f / (float)DSW, invh = 1.0f / (float)DSH;
     float r[DSH];
 #pragma unroll
@@ -509,7 +530,7 @@ __device__ __forceinline__ float llf_coeff(const DevFrame& f, const float* __res
 #pragma unroll
             for (int x = 1; x < DSW; ++x) d2 = d2 + row[x];
         } else {
-            const float* lut = lutw + (kx - 1) * DSW;
+            const cfloatp lut = lutw + (kx - 1) * DSW;
             d2 = row[0] * lut[0];
 #pragma unroll
             for (int n = 1; n < DSW; ++n) d2 = d2 + row[n] * lut[n];
@@ -522,7 +543,7 @@ __device__ __forceinline__ float llf_coeff(const DevFrame& f, const float* __res
 #pragma unroll
         for (int y = 1; y < DSH; ++y) d2 = d2 + r[y];
     } else {
-        const float* lut = luth + (ky - 1) * DSH;
+        const cfloatp lut = luth + (ky - 1) * DSH;
         d2 = r[0] * lut[0];
 #pragma unroll
         for (int n = 1; n < DSH; ++n) d2 = d2 + r[n] * lut[n];
@@ -556,6 +577,9 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
     constexpr int PI = JXL_TT[TYPE].param_index;
     constexpr bool FLIP = H >= W;  // TransformType.flip() for METHOD_DCT
     constexpr int DSH = H / 8, DSW = W / 8;
+    // rows prefetched per chunk of the column pass: 4 for the 16-row types keeps them within 64 VGPRs (8 waves per SIMD
+    // and a seat in the merged class-0 launch), 8 for the 8-row ones
+    constexpr int MAXRC = 8;
     // the 4 waves of the workgroup are independent: wave w owns blocks [w*BPW, (w+1)*BPW) of the item
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -572,27 +596,31 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
     const float* wy = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + 1];
     const float qbn = f.quant_bias_numerator;
     float* qtab = lds_wg + 4 * Cfg::BPW * IMG;
+    // the block record first: its load is in flight while the qbn/|q| table is built (the barrier would pin it behind)
+    const int bi_col = lane / W;
+    DevBlock b_col{};
+    if (bi_col < nb) b_col = load_block(blocks, wfirst + bi_col);
     if (wave == 0) qtab[lane] = lane > 0 ? qbn / (float)lane : 0.0f;
     __syncthreads();
 
     // ---- column pass
     {
-        const int bi = lane / W, x = lane % W;
+        const int bi = bi_col, x = lane % W;
         if (bi < nb) {
-            const DevBlock b = blocks[wfirst + bi];
+            const DevBlock b = b_col;
             const int py0 = b.cy * 8, px0 = b.cx * 8;
-            const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+            const float hfm = (float)b.hf_mul;
             const float sfc = f.scale_factor[c] / hfm, sfy = f.scale_factor[1] / hfm;
             const float qbc = f.quant_bias[c], qby = f.quant_bias[1];
             const int ty0 = py0 >> 6, tx0 = px0 >> 6;
             const int tx = (px0 + x) >> 6;
             const float* lfp = f.lf[c] + (int64_t)b.cy * f.bw + b.cx;
-            const float* lut = f.lut + lut_off(ceil_log2_dev(H));
+            const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(H)));
             float kcfl = 0.0f;
             MirrorAcc<H> acc;
             // rows in chunks of RC: all global loads of a chunk are issued before its arithmetic, so RC (x2-4)
             // loads per lane are in flight instead of one dependent load per row
-            constexpr int RC = 8;
+            constexpr int RC = MAXRC;
 #pragma unroll 1
             for (int n0 = 0; n0 < H; n0 += RC) {
                 int qcv[RC], qyv[RC];
@@ -643,9 +671,9 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
     {
         const int bi = lane / H, y = lane % H;
         if (bi < nb) {
-            const DevBlock b = blocks[wfirst + bi];
+            const DevBlock b = load_block(blocks, wfirst + bi);
             const float* row = lds + bi * IMG + y * LD;
-            const float* lut = f.lut + lut_off(ceil_log2_dev(W));
+            const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(W)));
             MirrorAcc<W> acc;
             acc.init(row[0]);
 #pragma unroll 4
@@ -731,8 +759,8 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         for (int bi = 0; bi < NBLK; bi++) {
             sfc_b[bi] = sfy_b[bi] = 0.0f;
             if (bi < nb) {
-                const DevBlock b = blocks[it.first + bi];
-                const float hfm = (float)f.hf_mul[b.cy * f.bw + b.cx];
+                const DevBlock b = load_block(blocks, (int)it.first + bi);
+                const float hfm = (float)b.hf_mul;
                 sfc_b[bi] = f.scale_factor[c] / hfm;
                 sfy_b[bi] = f.scale_factor[1] / hfm;
             }
@@ -743,7 +771,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             qcv[j] = qyv[j] = 0;
             wcv[j] = wyv[j] = 0.0f;
             if (bi < nb) {
-                const DevBlock b = blocks[it.first + bi];
+                const DevBlock b = load_block(blocks, (int)it.first + bi);
                 const int64_t off = (int64_t)(b.cy * 8 + n) * FW + b.cx * 8 + x;
                 qcv[j] = f.coeff[c][off];
                 wcv[j] = wc[n * W + x];
@@ -757,7 +785,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         for (int j = 0; j < NS; j++) {
             const int bi = j / BSTEP, n = (j % BSTEP) * RSTEP + r0;
             if (bi < nb) {
-                const DevBlock b = blocks[it.first + bi];
+                const DevBlock b = load_block(blocks, (int)it.first + bi);
                 const int py0 = b.cy * 8, px0 = b.cx * 8;
                 float co;
                 if (n < DSH && x < DSW) {
@@ -786,7 +814,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             // chunk kc = outputs [kc*KC/2, (kc+1)*KC/2) and their mirror images [H-(kc+1)*KC/2, H-kc*KC/2): one product
             // serves output k and output H-1-k (see idct1d_reg), so a lane keeps both halves of its KC outputs
             const float* src = img0 + bi * IMG + x;
-            const float* lut = f.lut + lut_off(ceil_log2_dev(H)) + kc * (KC / 2);
+            const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(H)) + kc * (KC / 2));
             MirrorAcc<KC> acc;
             acc.init(src[0]);
 #pragma unroll 2
@@ -809,9 +837,9 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         const int rr = tid % (NBLK * H), kc = __builtin_amdgcn_readfirstlane(tid / (NBLK * H));
         const int bi = rr / H, y = rr % H;
         if (bi < nb) {
-            const DevBlock b = blocks[it.first + bi];
+            const DevBlock b = load_block(blocks, (int)it.first + bi);
             const float* row = img1 + bi * IMG + y * LD;
-            const float* lut = f.lut + lut_off(ceil_log2_dev(W)) + kc * (KC / 2);
+            const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(W)) + kc * (KC / 2));
             MirrorAcc<KC> acc;
             acc.init(row[0]);
 #pragma unroll 2
@@ -836,50 +864,112 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
 // which types take the workgroup-level (LDS-staged, k-split) path instead of the wave-level streamed one
 __host__ __device__ constexpr bool use_wg_path(int h, int w) { return (h > w ? h : w) >= JXL_WG_PATH_MIN; }
 
-// ---- launches: one kernel per transform type present ------------------------------------------------------------
-// A single merged kernel (switch on the work item's type) was tried: hipcc allocates such a kernel 256 VGPRs +
-// scratch (code motion across the inlined branches; `amdgpu_num_vgpr` cannot be put on device functions), which
-// leaves one wave per SIMD. Per-type kernels keep their natural 59..150 VGPRs.
+// ---- launches: ONE kernel per register class, every transform type of the class in it -------------------------------
+// Per-type launches are individually too small to fill 256 CUs (a 4K frame has ~1000 waves of most types) and the
+// device runs at most 4 queues side by side, so a frame's 11 type kernels left most of the chip idle most of the time
+// (measured: GPU_MAX_HW_QUEUES 2 -> 4 is +35 %, beyond 4 nothing). A merged kernel is a type switch around the same
+// bodies; a workgroup is type-uniform, so nothing diverges. What makes it work:
+//  (1) classes by register need: class 0 = the types whose body fits 64 VGPRs (8 waves per SIMD; the minimum is part of
+//      __launch_bounds__ so the allocator is held to it -- without it the merged kernel came out at 256 VGPRs + scratch),
+//      class 2 = DCT16 / DCT16x8 (83 VGPRs), class 1 = the 64-point family (LDS-bound at 4 workgroups per CU anyway);
+//  (2) read-only tables through the constant address space (cfloatp, load_block): in a function this large the
+//      compiler no longer proves that the LUT / block records are never clobbered, and uniform loads silently turn
+//      into per-lane vector loads (the 64x64 body went from 173 to 330 us until this was done);
+//  (3) segments ordered longest-running type first, so the tail of the launch is made of the cheapest workgroups, with
+//      the XCD-aware order applied inside each segment;
+//  (4) work items are implicit (segment descriptors in the kernel arguments) and the block record carries hfMultiplier,
+//      so a workgroup's first dependent load is already its coefficients' address.
+// 4K mixed frame: 12 launches -> 4, IDCT stage 156 -> 128 us alone, 134 -> 114 us per frame in a batch of 8.
 template <int H, int W, int TYPE>
-__global__ __launch_bounds__(256) void k_idct_type(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                   const WorkItem* __restrict__ items, int n_items, float* o0, float* o1, float* o2) {
+__device__ __forceinline__ void type_body(const MultiArgs& a, int k, int li, float* lds) {
+    // implicit work item (jxl_internal.h): block group li / nch, channel ch0 + li % nch
+    constexpr int NB = use_wg_path(H, W) ? 64 / (H < W ? H : W) : 4 * (64 / (H > W ? H : W));
+    const int g = a.nch == 3 ? li / 3 : li;
+    const int ch = a.ch0 + (a.nch == 3 ? li - 3 * g : 0);
+    WorkItem it;
+    it.type = (uint32_t)TYPE | ((uint32_t)ch << 8);
+    it.first = (uint32_t)(a.seg_first[k] + g * NB);
+    it.count = (uint32_t)min(NB, a.seg_nblocks[k] - g * NB);
+    if constexpr (use_wg_path(H, W)) wg64_item<H, W, TYPE>(a.f, a.blocks, it, lds, a.o0, a.o1, a.o2);
+    else medium_item<H, W, TYPE>(a.f, a.blocks, it, lds, a.o0, a.o1, a.o2);
+}
+
+template <int CLASS>
+__global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi(const MultiArgs a) {
     extern __shared__ float lds[];
-    // XCD-aware item order (see k_restore_fused): each XCD takes a contiguous run of the spatially ordered items
-    const int per_xcd = (n_items + 7) >> 3;
-    const int idx = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (idx >= n_items) return;
-    if constexpr (use_wg_path(H, W)) wg64_item<H, W, TYPE>(f, blocks, items[idx], lds, o0, o1, o2);
-    else medium_item<H, W, TYPE>(f, blocks, items[idx], lds, o0, o1, o2);
+    const int b = (int)blockIdx.x;
+    int k = 0;
+    while (k + 1 < a.n_seg && b >= a.seg_b0[k + 1]) k++;
+    // XCD-aware item order inside the segment (see k_restore_fused): consecutive workgroup ids go to different XCDs, so
+    // XCD x takes the x-th contiguous run of the segment's spatially ordered items (chroma items re-read luma: L2 hits)
+    const int local = b - a.seg_b0[k], n = a.seg_n[k];
+    const int per_xcd = (n + 7) >> 3;
+    const int li = (local & 7) * per_xcd + (local >> 3);
+    if (li >= n) return;
+    const int t = a.seg_type[k];
+    if (CLASS == 0) {
+        switch (t) {
+        case 0: type_body<8, 8, 0>(a, k, li, lds); break;
+        case 5: type_body<32, 32, 5>(a, k, li, lds); break;
+        case 7: type_body<8, 16, 7>(a, k, li, lds); break;
+        case 8: type_body<32, 8, 8>(a, k, li, lds); break;
+        case 9: type_body<8, 32, 9>(a, k, li, lds); break;
+        case 10: type_body<32, 16, 10>(a, k, li, lds); break;
+        case 11: type_body<16, 32, 11>(a, k, li, lds); break;
+        default: break;
+        }
+    } else if (CLASS == 2) {
+        switch (t) {
+        case 4: type_body<16, 16, 4>(a, k, li, lds); break;
+        case 6: type_body<16, 8, 6>(a, k, li, lds); break;
+        default: break;
+        }
+    } else {
+        switch (t) {
+        case 18: type_body<64, 64, 18>(a, k, li, lds); break;
+        case 19: type_body<64, 32, 19>(a, k, li, lds); break;
+        case 20: type_body<32, 64, 20>(a, k, li, lds); break;
+        default: break;
+        }
+    }
 }
 
 size_t medium_lds_bytes(int type);
 
-template <int H, int W, int TYPE>
-static void launch_type_t(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n, float* const out[3],
-                          hipStream_t s) {
-    const size_t lds_bytes = medium_lds_bytes(TYPE);
-    hipLaunchKernelGGL((k_idct_type<H, W, TYPE>), dim3(((n + 7) / 8) * 8), dim3(256), lds_bytes, s, f, blocks, items, n, out[0], out[1], out[2]);
-}
+int idct_class_of(int type) { return (type == 18 || type == 19 || type == 20) ? 1 : (type == 4 || type == 6) ? 2 : 0; }
 
-// items: all of ONE type; WorkItem.type = type | channel << 8, up to medium_blocks_per_wg(type) blocks per item
-void launch_idct_type(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, int type, float* const out[3],
-                      hipStream_t s) {
-    if (n_items <= 0) return;
-    switch (type) {
-    case 0: launch_type_t<8, 8, 0>(f, blocks, items, n_items, out, s); break;
-    case 4: launch_type_t<16, 16, 4>(f, blocks, items, n_items, out, s); break;
-    case 5: launch_type_t<32, 32, 5>(f, blocks, items, n_items, out, s); break;
-    case 6: launch_type_t<16, 8, 6>(f, blocks, items, n_items, out, s); break;
-    case 7: launch_type_t<8, 16, 7>(f, blocks, items, n_items, out, s); break;
-    case 8: launch_type_t<32, 8, 8>(f, blocks, items, n_items, out, s); break;
-    case 9: launch_type_t<8, 32, 9>(f, blocks, items, n_items, out, s); break;
-    case 10: launch_type_t<32, 16, 10>(f, blocks, items, n_items, out, s); break;
-    case 11: launch_type_t<16, 32, 11>(f, blocks, items, n_items, out, s); break;
-    case 18: launch_type_t<64, 64, 18>(f, blocks, items, n_items, out, s); break;
-    case 19: launch_type_t<64, 32, 19>(f, blocks, items, n_items, out, s); break;
-    case 20: launch_type_t<32, 64, 20>(f, blocks, items, n_items, out, s); break;
-    default: break;
+// segs: the class's types in launch order
+void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const IdctSegment* segs, int n_seg, int nch, int ch0,
+                       float* const out[3], hipStream_t s) {
+    if (n_seg <= 0) return;
+    MultiArgs a;
+    a.f = f;
+    a.blocks = blocks;
+    a.items = nullptr;
+    a.o0 = out[0]; a.o1 = out[1]; a.o2 = out[2];
+    a.nch = nch;
+    a.ch0 = ch0;
+    a.n_seg = 0;
+    int b0 = 0;
+    size_t lds_bytes = 0;
+    for (int i = 0; i < n_seg && a.n_seg < MultiArgs::kMaxSeg; i++) {
+        if (segs[i].n_blocks <= 0) continue;
+        const int k = a.n_seg++;
+        const int nb = medium_blocks_per_wg(segs[i].type);
+        const int n_items = ((segs[i].n_blocks + nb - 1) / nb) * nch;
+        a.seg_b0[k] = b0;
+        a.seg_n[k] = n_items;
+        a.seg_type[k] = segs[i].type;
+        a.seg_first[k] = segs[i].first_block;
+        a.seg_nblocks[k] = segs[i].n_blocks;
+        b0 += ((n_items + 7) / 8) * 8;
+        lds_bytes = std::max(lds_bytes, medium_lds_bytes(segs[i].type));
     }
+    if (a.n_seg == 0) return;
+    for (int k = a.n_seg; k <= MultiArgs::kMaxSeg; k++) a.seg_b0[k] = b0;
+    if (cls == 0) hipLaunchKernelGGL(k_idct_multi<0>, dim3(b0), dim3(256), lds_bytes, s, a);
+    else if (cls == 2) hipLaunchKernelGGL(k_idct_multi<2>, dim3(b0), dim3(256), lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_idct_multi<1>, dim3(b0), dim3(256), lds_bytes, s, a);
 }
 
 // blocks of one channel that one workgroup (work item) handles
