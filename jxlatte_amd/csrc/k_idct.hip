@@ -688,6 +688,107 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
     }
 }
 
+// The same transform for all three channels of the wave's blocks, luma first: the dequantised luma column stays in
+// registers and feeds chromaFromLuma of X and B, instead of being loaded and dequantised again by separate chroma work
+// items (5 coefficient + 5 weight loads and 5 dequantisations per pixel become 3 + 3 + 3). Used for frames without
+// chroma subsampling; the channel loop is rolled, so the code size is that of medium_item.
+template <int H, int W, int TYPE>
+__device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* __restrict__ blocks, const WorkItem it,
+                                             float* __restrict__ lds_wg, float* __restrict__ o0, float* __restrict__ o1,
+                                             float* __restrict__ o2) {
+    using Cfg = MediumCfg<H, W>;
+    constexpr int LD = Cfg::LD, IMG = Cfg::IMG;
+    constexpr int PI = JXL_TT[TYPE].param_index;
+    constexpr bool FLIP = H >= W;  // TransformType.flip() for METHOD_DCT
+    constexpr int DSH = H / 8, DSW = W / 8;
+    constexpr int RC = 8;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wfirst = (int)it.first + wave * Cfg::BPW;
+    const int nb = min(max((int)it.count - wave * Cfg::BPW, 0), Cfg::BPW);
+    float* lds = lds_wg + wave * (Cfg::BPW * IMG);
+    const int FW = f.width;
+    const float qbn = f.quant_bias_numerator;
+    float* qtab = lds_wg + 4 * Cfg::BPW * IMG;
+    const int bi_col = lane / W, x = lane % W;
+    const int bi_row = lane / H, y = lane % H;
+    DevBlock b_col{}, b_row{};
+    if (bi_col < nb) b_col = load_block(blocks, wfirst + bi_col);
+    if (bi_row < nb) b_row = load_block(blocks, wfirst + bi_row);
+    if (wave == 0) qtab[lane] = lane > 0 ? qbn / (float)lane : 0.0f;
+    __syncthreads();
+    const int py0 = b_col.cy * 8, px0 = b_col.cx * 8;
+    const float hfm = (float)b_col.hf_mul;
+    const int ty0 = py0 >> 6, tx0 = px0 >> 6;
+    const int tx = (px0 + x) >> 6;
+    const cfloatp lut_h = as_const(f.lut + lut_off(ceil_log2_dev(H)));
+    const cfloatp lut_w = as_const(f.lut + lut_off(ceil_log2_dev(W)));
+    float dyv[H];  // dequantised luma of this lane's column (HFCoefficients.java:186-188 reads it for X and B)
+#pragma unroll
+    for (int n = 0; n < H; n++) dyv[n] = 0.0f;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; pass++) {
+        const int c = pass == 0 ? 1 : pass == 1 ? 0 : 2;
+        // ---- column pass
+        if (bi_col < nb) {
+            const int* qc_plane = f.coeff[c];
+            const float* wc = (FLIP ? f.weights_t : f.weights) + f.woffs[PI * 3 + c];
+            const float sfc = f.scale_factor[c] / hfm;
+            const float qbc = f.quant_bias[c];
+            const float* lfp = f.lf[c] + (int64_t)b_col.cy * f.bw + b_col.cx;
+            float kcfl = 0.0f;
+            MirrorAcc<H> acc;
+#pragma unroll
+            for (int n0 = 0; n0 < H; n0 += RC) {
+                int qcv[RC];
+                float wcv[RC];
+                const int64_t off0 = (int64_t)(py0 + n0) * FW + px0 + x;
+#pragma unroll
+                for (int r = 0; r < RC; r++) {
+                    qcv[r] = qc_plane[off0 + (int64_t)r * FW];
+                    wcv[r] = wc[(n0 + r) * W + x];  // (FLIP ? transposed table : table)[n][x]
+                }
+#pragma unroll
+                for (int r = 0; r < RC; r++) {
+                    const int n = n0 + r;
+                    if (c != 1 && (n == 0 || ((py0 + n) & 63) == 0)) {  // entering a new CfL tile row
+                        const int ty = (py0 + n) >> 6;
+                        float kX, kB;
+                        cfl_factors(f, ty, tx, (b_col.cfl_zero >> ((ty - ty0) * 5 + (tx - tx0))) & 1u, kX, kB);
+                        kcfl = c == 0 ? kX : kB;
+                    }
+                    float co = dequant1_tab(qcv[r], qbc, qbn, sfc, wcv[r], qtab);
+                    if (c == 1) dyv[n] = co;
+                    else co = co + kcfl * dyv[n];  // chromaFromLuma (:186-188)
+                    if (n < DSH && x < DSW) co = llf_coeff<DSH, DSW>(f, lfp, n, x);  // finalizeLLF (:194-229)
+                    if (n == 0) acc.init(co);
+                    else if (r & 1) acc.template step<true>(co, lut_h + (n - 1) * H);
+                    else acc.template step<false>(co, lut_h + (n - 1) * H);
+                }
+            }
+            float* dcol = lds + bi_col * IMG + x;
+#pragma unroll
+            for (int k = 0; k < H; k++) dcol[k * LD] = acc.get(k);
+        }
+        __syncthreads();  // orders the wave's LDS image for the row pass (all 4 waves run the same sequence)
+        // ---- row pass
+        if (bi_row < nb) {
+            const float* row = lds + bi_row * IMG + y * LD;
+            MirrorAcc<W> acc;
+            acc.init(row[0]);
+#pragma unroll 4
+            for (int n = 1; n < W; n += 2) {  // (odd, even) pairs; W is even, so the last odd n stands alone
+                acc.template step<true>(row[n], lut_w + (n - 1) * W);
+                if (n + 1 < W) acc.template step<false>(row[n + 1], lut_w + n * W);
+            }
+            float* o = (c == 0 ? o0 : c == 1 ? o1 : o2) + (int64_t)(b_row.cy * 8 + y) * FW + b_row.cx * 8;
+#pragma unroll
+            for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(o + k) = make_float4(acc.get(k), acc.get(k + 1), acc.get(k + 2), acc.get(k + 3));
+        }
+        __syncthreads();  // the image is free for the next channel's column pass
+    }
+}
+
 // finalizeLLF (HFCoefficients.java:194-229) of every block larger than 8x8, written over the block's own cells
 // of the llf planes (a block covers exactly dctSelectHeight x dctSelectWidth cells). grid = (3, nblocks).
 __global__ __launch_bounds__(256) void k_llf(const DevFrame f, const DevBlock* __restrict__ blocks, int first, float* l0, float* l1,
@@ -880,21 +981,24 @@ __host__ __device__ constexpr bool use_wg_path(int h, int w) { return (h > w ? h
 //  (4) work items are implicit (segment descriptors in the kernel arguments) and the block record carries hfMultiplier,
 //      so a workgroup's first dependent load is already its coefficients' address.
 // 4K mixed frame: 12 launches -> 4, IDCT stage 156 -> 128 us alone, 134 -> 114 us per frame in a batch of 8.
-template <int H, int W, int TYPE>
+// ALLCH (frames without chroma subsampling): a wave-path item is a block group with all three channels (medium_item3);
+// everything else -- the LDS-staged types, and every type of a per-channel launch -- is (block group, channel)
+template <int H, int W, int TYPE, bool ALLCH>
 __device__ __forceinline__ void type_body(const MultiArgs& a, int k, int li, float* lds) {
-    // implicit work item (jxl_internal.h): block group li / nch, channel ch0 + li % nch
     constexpr int NB = use_wg_path(H, W) ? 64 / (H < W ? H : W) : 4 * (64 / (H > W ? H : W));
-    const int g = a.nch == 3 ? li / 3 : li;
-    const int ch = a.ch0 + (a.nch == 3 ? li - 3 * g : 0);
+    constexpr bool ITEM3 = ALLCH && !use_wg_path(H, W);
+    const int g = ITEM3 ? li : ALLCH ? li / 3 : li;
+    const int ch = ITEM3 ? 0 : ALLCH ? li - 3 * g : a.ch0;
     WorkItem it;
     it.type = (uint32_t)TYPE | ((uint32_t)ch << 8);
     it.first = (uint32_t)(a.seg_first[k] + g * NB);
     it.count = (uint32_t)min(NB, a.seg_nblocks[k] - g * NB);
     if constexpr (use_wg_path(H, W)) wg64_item<H, W, TYPE>(a.f, a.blocks, it, lds, a.o0, a.o1, a.o2);
+    else if constexpr (ALLCH) medium_item3<H, W, TYPE>(a.f, a.blocks, it, lds, a.o0, a.o1, a.o2);
     else medium_item<H, W, TYPE>(a.f, a.blocks, it, lds, a.o0, a.o1, a.o2);
 }
 
-template <int CLASS>
+template <int CLASS, bool ALLCH>
 __global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi(const MultiArgs a) {
     extern __shared__ float lds[];
     const int b = (int)blockIdx.x;
@@ -909,26 +1013,26 @@ __global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi(const Mu
     const int t = a.seg_type[k];
     if (CLASS == 0) {
         switch (t) {
-        case 0: type_body<8, 8, 0>(a, k, li, lds); break;
-        case 5: type_body<32, 32, 5>(a, k, li, lds); break;
-        case 7: type_body<8, 16, 7>(a, k, li, lds); break;
-        case 8: type_body<32, 8, 8>(a, k, li, lds); break;
-        case 9: type_body<8, 32, 9>(a, k, li, lds); break;
-        case 10: type_body<32, 16, 10>(a, k, li, lds); break;
-        case 11: type_body<16, 32, 11>(a, k, li, lds); break;
+        case 0: type_body<8, 8, 0, ALLCH>(a, k, li, lds); break;
+        case 5: type_body<32, 32, 5, ALLCH>(a, k, li, lds); break;
+        case 7: type_body<8, 16, 7, ALLCH>(a, k, li, lds); break;
+        case 8: type_body<32, 8, 8, ALLCH>(a, k, li, lds); break;
+        case 9: type_body<8, 32, 9, ALLCH>(a, k, li, lds); break;
+        case 10: type_body<32, 16, 10, ALLCH>(a, k, li, lds); break;
+        case 11: type_body<16, 32, 11, ALLCH>(a, k, li, lds); break;
         default: break;
         }
     } else if (CLASS == 2) {
         switch (t) {
-        case 4: type_body<16, 16, 4>(a, k, li, lds); break;
-        case 6: type_body<16, 8, 6>(a, k, li, lds); break;
+        case 4: type_body<16, 16, 4, ALLCH>(a, k, li, lds); break;
+        case 6: type_body<16, 8, 6, ALLCH>(a, k, li, lds); break;
         default: break;
         }
     } else {
         switch (t) {
-        case 18: type_body<64, 64, 18>(a, k, li, lds); break;
-        case 19: type_body<64, 32, 19>(a, k, li, lds); break;
-        case 20: type_body<32, 64, 20>(a, k, li, lds); break;
+        case 18: type_body<64, 64, 18, ALLCH>(a, k, li, lds); break;
+        case 19: type_body<64, 32, 19, ALLCH>(a, k, li, lds); break;
+        case 20: type_body<32, 64, 20, ALLCH>(a, k, li, lds); break;
         default: break;
         }
     }
@@ -956,7 +1060,9 @@ void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const
         if (segs[i].n_blocks <= 0) continue;
         const int k = a.n_seg++;
         const int nb = medium_blocks_per_wg(segs[i].type);
-        const int n_items = ((segs[i].n_blocks + nb - 1) / nb) * nch;
+        const int tt_h = JXL_TT[segs[i].type].ph, tt_w = JXL_TT[segs[i].type].pw;
+        const bool item3 = nch == 3 && !use_wg_path(tt_h, tt_w);  // one item = all three channels of a block group
+        const int n_items = ((segs[i].n_blocks + nb - 1) / nb) * (item3 ? 1 : nch);
         a.seg_b0[k] = b0;
         a.seg_n[k] = n_items;
         a.seg_type[k] = segs[i].type;
@@ -967,9 +1073,16 @@ void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const
     }
     if (a.n_seg == 0) return;
     for (int k = a.n_seg; k <= MultiArgs::kMaxSeg; k++) a.seg_b0[k] = b0;
-    if (cls == 0) hipLaunchKernelGGL(k_idct_multi<0>, dim3(b0), dim3(256), lds_bytes, s, a);
-    else if (cls == 2) hipLaunchKernelGGL(k_idct_multi<2>, dim3(b0), dim3(256), lds_bytes, s, a);
-    else hipLaunchKernelGGL(k_idct_multi<1>, dim3(b0), dim3(256), lds_bytes, s, a);
+    const dim3 grid(b0), wg(256);
+    if (nch == 3) {
+        if (cls == 0) hipLaunchKernelGGL((k_idct_multi<0, true>), grid, wg, lds_bytes, s, a);
+        else if (cls == 2) hipLaunchKernelGGL((k_idct_multi<2, true>), grid, wg, lds_bytes, s, a);
+        else hipLaunchKernelGGL((k_idct_multi<1, true>), grid, wg, lds_bytes, s, a);
+    } else {
+        if (cls == 0) hipLaunchKernelGGL((k_idct_multi<0, false>), grid, wg, lds_bytes, s, a);
+        else if (cls == 2) hipLaunchKernelGGL((k_idct_multi<2, false>), grid, wg, lds_bytes, s, a);
+        else hipLaunchKernelGGL((k_idct_multi<1, false>), grid, wg, lds_bytes, s, a);
+    }
 }
 
 // blocks of one channel that one workgroup (work item) handles
