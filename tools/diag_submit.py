@@ -1,6 +1,6 @@
 """is the batch step bound by host-side launch cost?  submit time (no sync) vs total time per step"""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from jxlatte_amd import _lib, host, synth
 st = int(sys.argv[1]) if len(sys.argv) > 1 else 31
