@@ -1496,7 +1496,12 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
             if (!o.d) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze output)");
             o.original = false;
             op.a = a.d; op.b = re.d; op.o = o.d;
-            batch.bt.d[batch.bt.n++] = SqueezeDesc{a.d, re.d, o.d, op.adim, op.rdim, op.other};
+            SqueezeDesc sd{a.d, re.d, o.d, op.adim, op.rdim, op.other, nullptr};
+            if (op.rdim > kSqueezeSeg && !getenv("JXL_SQUEEZE_SERIAL")) {  // segmented walk: chain state per segment start
+                sd.side = alloc((size_t)((op.rdim + kSqueezeSeg - 1) / kSqueezeSeg) * op.other);
+                if (!sd.side) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze segment states)");
+            }
+            batch.bt.d[batch.bt.n++] = sd;
             if (batch.bt.n == 8) {
                 c->mod_ops.push_back(batch);
                 batch.bt.n = 0;

@@ -117,32 +117,42 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
     const int w = d.other, ah = d.adim, rh = d.rdim;
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
+    // segment of pair rows [yb, ye) stored by this wave; the walk starts kSqueezeWarm pairs earlier (jxl_internal.h)
+    const int nseg = squeeze_segments(d);
+    const int s = blockIdx.z;
+    if (s >= nseg) return;
+    const int yb = s * kSqueezeSeg;
+    const int ye = nseg == 1 ? rh : min(rh, yb + kSqueezeSeg);
+    const int ys = s > 0 ? yb - kSqueezeWarm : 0;
     const int32_t* __restrict__ avg = d.a;
     const int32_t* __restrict__ res = d.b;
     int32_t* __restrict__ out = d.o;
     constexpr int RV = 8;
+    static_assert(kSqueezeWarm % RV == 0 && kSqueezeSeg % RV == 0, "segment and warm-up boundaries fall on chunk boundaries");
     int32_t top = 0;
-    int32_t a = rh > 0 ? avg[x] : 0;
-    // software pipeline: the loads of chunk k+1 are issued before the serial chain of chunk k runs, so a lone wave (this
-    // step has far fewer waves than the chip has SIMDs) does not sit in s_waitcnt for a full memory round trip per chunk
+    int32_t a = rh > 0 ? avg[(int64_t)ys * w + x] : 0;
+    // software pipeline: the loads of chunk k+1 are issued before the serial chain of chunk k runs, so a lone wave
+    // does not sit in s_waitcnt for a full memory round trip per chunk
     int32_t rr_n[RV], na_n[RV];
-    auto fetch = [&](int yb, int32_t* r_, int32_t* n_) {
+    auto fetch = [&](int yb_, int32_t* r_, int32_t* n_) {
 #pragma unroll
         for (int i = 0; i < RV; i++) {
-            const int y = yb + i;
+            const int y = yb_ + i;
             r_[i] = y < rh ? res[(int64_t)y * w + x] : 0;
             n_[i] = (y < rh && y + 1 < ah) ? avg[(int64_t)(y + 1) * w + x] : 0;
         }
     };
-    fetch(0, rr_n, na_n);
-    for (int y0 = 0; y0 < rh; y0 += RV) {
+    fetch(ys, rr_n, na_n);
+    for (int y0 = ys; y0 < ye; y0 += RV) {
+        if (y0 == yb && s > 0) d.side[(int64_t)s * w + x] = top;  // the state this wave starts its own segment from
+        const bool keep = y0 >= yb;                                // warm-up chunks store nothing
         int32_t rr[RV], na[RV];
 #pragma unroll
         for (int i = 0; i < RV; i++) {
             rr[i] = rr_n[i];
             na[i] = na_n[i];
         }
-        if (y0 + RV < rh) fetch(y0 + RV, rr_n, na_n);
+        if (y0 + RV < ye) fetch(y0 + RV, rr_n, na_n);
         // everything that does not depend on the recurrence first
         int32_t av[RV + 1];
         TendPre tp[RV];
@@ -153,12 +163,13 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
             av[i + 1] = y + 1 < ah ? na[i] : av[i];
             tp[i] = tend_pre(av[i], av[i + 1]);
         }
-        if (y0 + RV <= rh) {  // full chunk: no guards on the serial chain, stores after it
+        if (y0 + RV <= ye) {  // full chunk: no guards on the serial chain, stores after it
             int32_t o1[RV], o2[RV];
             TendFast tf[RV];
 #pragma unroll
             for (int i = 0; i < RV; i++) tf[i] = tend_fast_pre(av[i], av[i + 1]);
-            const int32_t top0 = y0 > 0 ? top : av[0];  // the first pair of a column uses its own average as `left`
+            // the first pair of a column uses its own average as `left`; a warm-up start guesses the same
+            const int32_t top0 = y0 > ys ? top : av[0];
             top = top0;
             bool unsafe = false;
 #pragma unroll
@@ -178,30 +189,70 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
                     top = o2[i];
                 }
             }
+            if (keep) {
 #pragma unroll
-            for (int i = 0; i < RV; i++) {
-                out[(int64_t)(2 * (y0 + i)) * w + x] = o1[i];
-                out[(int64_t)(2 * (y0 + i) + 1) * w + x] = o2[i];
+                for (int i = 0; i < RV; i++) {
+                    out[(int64_t)(2 * (y0 + i)) * w + x] = o1[i];
+                    out[(int64_t)(2 * (y0 + i) + 1) * w + x] = o2[i];
+                }
             }
             a = av[RV];
         } else {
 #pragma unroll
             for (int i = 0; i < RV; i++) {
                 const int y = y0 + i;
-                if (y < rh) {
-                    const int32_t t = y > 0 ? top : av[i];
+                if (y < ye) {
+                    const int32_t t = y > ys ? top : av[i];
                     const int32_t diff = wadd(rr[i], tend_apply(t, tp[i]));
                     const int32_t first = wadd(av[i], diff / 2);
                     const int32_t second = wsub(first, diff);
-                    out[(int64_t)(2 * y) * w + x] = first;
-                    out[(int64_t)(2 * y + 1) * w + x] = second;
+                    if (keep) {
+                        out[(int64_t)(2 * y) * w + x] = first;
+                        out[(int64_t)(2 * y + 1) * w + x] = second;
+                    }
                     top = second;
                     a = av[i + 1];
                 }
             }
         }
     }
-    if (ah > rh) out[(int64_t)(2 * rh) * w + x] = avg[(int64_t)rh * w + x];
+    if (s == 0 && ah > rh) out[(int64_t)(2 * rh) * w + x] = avg[(int64_t)rh * w + x];
+}
+
+// Check of the segmented walk (jxl_internal.h): lane = column (V) or row (H). A boundary is good when the state the
+// segment's wave reached after its warm-up equals the last output of the previous segment; the lane redoes its
+// column / row serially from the first bad boundary (everything before it is exact by induction).
+__global__ __launch_bounds__(64) void k_squeeze_verify(const SqueezeBatch bt) {
+    const SqueezeDesc d = bt.d[blockIdx.y];
+    const int nseg = squeeze_segments(d);
+    if (nseg <= 1) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;  // column (V) or row (H)
+    if (i >= d.other) return;
+    const int n = d.other, adim = d.adim, rdim = d.rdim;
+    const int32_t* __restrict__ avg = d.a;
+    const int32_t* __restrict__ res = d.b;
+    int32_t* out = d.o;
+    const bool hz = bt.horizontal != 0;
+    const int ow = adim + rdim;
+    // element k of the squeezed axis of lane i
+    auto at_a = [&](int k) { return hz ? avg[(int64_t)i * adim + k] : avg[(int64_t)k * n + i]; };
+    auto at_r = [&](int k) { return hz ? res[(int64_t)i * rdim + k] : res[(int64_t)k * n + i]; };
+    auto po = [&](int k) { return hz ? out + (int64_t)i * ow + k : out + (int64_t)k * n + i; };
+    int bad = 0;
+    for (int s = nseg - 1; s >= 1; s--)
+        if (d.side[(int64_t)s * n + i] != *po(2 * s * kSqueezeSeg - 1)) bad = s;
+    if (__builtin_expect(bad == 0, 1)) return;
+    int32_t left = *po(2 * bad * kSqueezeSeg - 1);
+    for (int k = bad * kSqueezeSeg; k < rdim; k++) {
+        const int32_t a = at_a(k);
+        const int32_t nx = k + 1 < adim ? at_a(k + 1) : a;
+        const int32_t diff = wadd(at_r(k), tendency(left, a, nx));
+        const int32_t first = wadd(a, diff / 2);
+        const int32_t second = wsub(first, diff);
+        *po(2 * k) = first;
+        *po(2 * k + 1) = second;
+        left = second;
+    }
 }
 
 // inverseHorizontalSqueeze (ModularChannel.java:361-387): lane = row. 64-row x 64-column chunks of avg/res are
@@ -213,6 +264,13 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
     const int aw = d.adim, rw = d.rdim, h = d.other;
     const int y0 = blockIdx.x * 64;
     if (y0 >= h) return;
+    // segment of pairs [xb, xe) stored by this wave; the walk starts kSqueezeWarm pairs earlier (jxl_internal.h)
+    const int nseg = squeeze_segments(d);
+    const int s = blockIdx.z;
+    if (s >= nseg) return;
+    const int xb = s * kSqueezeSeg;
+    const int xe = nseg == 1 ? rw : min(rw, xb + kSqueezeSeg);
+    const int xs = s > 0 ? xb - kSqueezeWarm : 0;
     const int32_t* __restrict__ avg = d.a;
     const int32_t* __restrict__ res = d.b;
     int32_t* __restrict__ out = d.o;
@@ -222,8 +280,9 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
     const int rows = min(64, h - y0);
     const int ow = aw + rw;
     int32_t left = 0;
-    for (int x0 = 0; x0 < rw; x0 += 64) {
-        const int cols = min(64, rw - x0);
+    for (int x0 = xs; x0 < xe;) {
+        const bool warm = x0 < xb;  // the warm-up chunk: walked, not stored
+        const int cols = warm ? xb - x0 : min(64, xe - x0);
         __syncthreads();
         if (rows == 64 && cols == 64) {  // fast path: all 128 row loads in flight, then the LDS writes
             int32_t ta[64], tr[64];
@@ -269,7 +328,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
                     TendFast tf[U];
 #pragma unroll
                     for (int j = 0; j < U; j++) tf[j] = tend_fast_pre(va[j], va[j + 1]);
-                    const int32_t left0 = (x0 + i0) > 0 ? left : va[0];  // the first pair of a row uses its own average
+                    const int32_t left0 = (x0 + i0) > xs ? left : va[0];  // the first pair of a row uses its own average; a warm-up start guesses the same
                     left = left0;
                     bool unsafe = false;
 #pragma unroll
@@ -312,7 +371,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
 #pragma unroll
                     for (int j = 0; j < U; j++) {
                         const int i = i0 + j;
-                        const int32_t l = (x0 + i) > 0 ? left : va[j];
+                        const int32_t l = (x0 + i) > xs ? left : va[j];
                         const int32_t diff = wadd(vr[j], tend_apply(l, tp[j]));
                         const int32_t first = wadd(va[j], diff / 2);
                         const int32_t second = wsub(first, diff);
@@ -326,24 +385,33 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
             }
         }
         __syncthreads();
-        for (int r = 0; r < rows; r++) {
-            const int64_t ro = (int64_t)(y0 + r) * ow + 2 * x0;
-            const int j0 = lane, j1 = lane + 64;
-            if (j0 < 2 * cols) out[ro + j0] = (j0 & 1) ? sR[r * 65 + (j0 >> 1)] : sA[r * 65 + (j0 >> 1)];
-            if (j1 < 2 * cols) out[ro + j1] = (j1 & 1) ? sR[r * 65 + (j1 >> 1)] : sA[r * 65 + (j1 >> 1)];
+        if (warm) {
+            if (lane < rows) d.side[(int64_t)s * h + y0 + lane] = left;  // the state this wave starts its own segment from
+        } else {
+            for (int r = 0; r < rows; r++) {
+                const int64_t ro = (int64_t)(y0 + r) * ow + 2 * x0;
+                const int j0 = lane, j1 = lane + 64;
+                if (j0 < 2 * cols) out[ro + j0] = (j0 & 1) ? sR[r * 65 + (j0 >> 1)] : sA[r * 65 + (j0 >> 1)];
+                if (j1 < 2 * cols) out[ro + j1] = (j1 & 1) ? sR[r * 65 + (j1 >> 1)] : sA[r * 65 + (j1 >> 1)];
+            }
         }
+        x0 += cols;
     }
-    if (aw > rw && lane < rows) out[(int64_t)(y0 + lane) * ow + 2 * rw] = avg[(int64_t)(y0 + lane) * aw + rw];
+    if (s == 0 && aw > rw && lane < rows) out[(int64_t)(y0 + lane) * ow + 2 * rw] = avg[(int64_t)(y0 + lane) * aw + rw];
 }
 
 void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s) {
     if (bt.n <= 0) return;
-    int maxdim = 0;
-    for (int i = 0; i < bt.n; i++) maxdim = bt.d[i].other > maxdim ? bt.d[i].other : maxdim;
+    int maxdim = 0, nseg = 1;
+    for (int i = 0; i < bt.n; i++) {
+        maxdim = bt.d[i].other > maxdim ? bt.d[i].other : maxdim;
+        nseg = squeeze_segments(bt.d[i]) > nseg ? squeeze_segments(bt.d[i]) : nseg;
+    }
     if (maxdim <= 0) return;
-    const dim3 grid((maxdim + 63) / 64, bt.n);
+    const dim3 grid((maxdim + 63) / 64, bt.n, nseg);
     if (bt.horizontal) hipLaunchKernelGGL(k_inv_hsqueeze, grid, dim3(64), 0, s, bt);
     else hipLaunchKernelGGL(k_inv_vsqueeze, grid, dim3(64), 0, s, bt);
+    if (nseg > 1) hipLaunchKernelGGL(k_squeeze_verify, dim3((maxdim + 63) / 64, bt.n), dim3(64), 0, s, bt);
 }
 
 void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out, hipStream_t s) {
@@ -351,7 +419,7 @@ void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw,
     SqueezeBatch bt{};
     bt.n = 1;
     bt.horizontal = 1;
-    bt.d[0] = SqueezeDesc{avg, res, out, aw, rw, h};
+    bt.d[0] = SqueezeDesc{avg, res, out, aw, rw, h, nullptr};
     launch_squeeze_batch(bt, s);
 }
 
@@ -360,7 +428,7 @@ void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh,
     SqueezeBatch bt{};
     bt.n = 1;
     bt.horizontal = 0;
-    bt.d[0] = SqueezeDesc{avg, res, out, ah, rh, w};
+    bt.d[0] = SqueezeDesc{avg, res, out, ah, rh, w, nullptr};
     launch_squeeze_batch(bt, s);
 }
 

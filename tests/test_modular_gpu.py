@@ -108,3 +108,54 @@ def test_squeeze_round_trip_property_full_size(ctx, orc):
             chans.insert(offset + k - begin, r)
     out = host.ModularStream(ctx, chans, sp).applyTransforms()
     assert len(out) == 1 and np.array_equal(out[0], img)
+
+
+# ---- the segmented walk (jxl_internal.h, kSqueezeSeg / kSqueezeWarm): one-step plans through jxl_modular_begin
+def _one_step(ctx, orc, avg, res, horizontal):
+    sp = [(1 if horizontal else 0, 1, 0, 1)]
+    out = host.ModularStream(ctx, [avg, res], sp).applyTransforms()
+    exp = orc.modular_apply([avg, res], sp)
+    assert len(out) == len(exp) == 1
+    return out[0], exp[0]
+
+
+@pytest.mark.parametrize("n,other", [(65, 3), (128, 64), (129, 70), (500, 130), (1000, 5)])
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_segmented_squeeze_random(ctx, orc, n, other, horizontal):
+    """axis longer than one segment, odd and even totals, ragged last segment, several row / column blocks"""
+    rng = np.random.default_rng(n * 7 + other)
+    for odd in (0, 1):
+        a = rng.integers(-3000, 3000, size=(other, n + odd)).astype(np.int32)
+        r = np.rint(rng.laplace(0, 40, size=(other, n))).astype(np.int32)
+        if not horizontal:
+            a, r = a.T.copy(), r.T.copy()
+        got, exp = _one_step(ctx, orc, a, r, horizontal)
+        assert_bits_equal(got, exp, "segmented %s n=%d odd=%d" % ("h" if horizontal else "v", n, odd))
+
+
+def _adversarial(n, other):
+    """Rows whose recurrence never forgets its start: with avg falling by 1000 per pair and residual 1992 the chain sits
+    in the slope-2 clamp of tendency(), where (left - avg) = u maps to 3 - u: the true walk cycles 2,1,2,1 (residual
+    1994 on the first pair puts it there), a walk started from the guessed state cycles 0,3,0,3. Every segment boundary
+    mismatches, so the verification kernel has to redo the rows serially. Row 1 is ordinary data."""
+    a = np.empty((other, n), np.int64)
+    a[:] = 10_000_000 - 1000 * np.arange(n)
+    r = np.full((other, n), 1992, np.int64)
+    r[:, 0] = 1994
+    rng = np.random.default_rng(5)
+    a[1] = rng.integers(-3000, 3000, size=n)
+    r[1] = np.rint(rng.laplace(0, 40, size=n))
+    return a.astype(np.int32), r.astype(np.int32)
+
+
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_segmented_squeeze_adversarial(ctx, orc, horizontal):
+    a, r = _adversarial(300, 70)
+    # the construction does what it says: walking row 0 from the guess at pair 48 never meets the true walk
+    t = orc.inv_hsqueeze(a[:1], r[:1])[0]
+    u_true = (t[1::2][:-1].astype(np.int64) - a[0, 1:]) % 4
+    assert set(u_true[40:80].tolist()) <= {1, 2}
+    if not horizontal:
+        a, r = a.T.copy(), r.T.copy()
+    got, exp = _one_step(ctx, orc, a, r, horizontal)
+    assert_bits_equal(got, exp, "adversarial %s" % ("h" if horizontal else "v"))
