@@ -274,33 +274,37 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
     const int32_t* __restrict__ avg = d.a;
     const int32_t* __restrict__ res = d.b;
     int32_t* __restrict__ out = d.o;
-    __shared__ int32_t sA[64 * 65];  // avg chunk [row][col]; overwritten in place by the even outputs
-    __shared__ int32_t sR[64 * 65];  // res chunk [row][col]; overwritten in place by the odd outputs
+    // 64 rows x CW pairs per LDS chunk. CW = 32 (17 KB per wave, 9 waves per CU) instead of 64 (33 KB, 4 waves per CU):
+    // the segmented walk has thousands of waves per step, and the LDS chunk was what kept all but 4 per CU waiting
+    constexpr int CW = 32, LDW = CW + 1, RPI = 64 / CW;  // row stride; rows covered by one wave-wide load
+    __shared__ int32_t sA[64 * LDW];  // avg chunk [row][col]; overwritten in place by the even outputs
+    __shared__ int32_t sR[64 * LDW];  // res chunk [row][col]; overwritten in place by the odd outputs
+    const int lc = threadIdx.x % CW, lr = threadIdx.x / CW;
     const int lane = threadIdx.x;
     const int rows = min(64, h - y0);
     const int ow = aw + rw;
     int32_t left = 0;
     for (int x0 = xs; x0 < xe;) {
         const bool warm = x0 < xb;  // the warm-up chunk: walked, not stored
-        const int cols = warm ? xb - x0 : min(64, xe - x0);
+        const int cols = warm ? xb - x0 : min(CW, xe - x0);
         __syncthreads();
-        if (rows == 64 && cols == 64) {  // fast path: all 128 row loads in flight, then the LDS writes
-            int32_t ta[64], tr[64];
+        if (rows == 64 && cols == CW) {  // fast path: all row loads in flight, then the LDS writes
+            int32_t ta[CW], tr[CW];
 #pragma unroll
-            for (int r = 0; r < 64; r++) {
-                ta[r] = avg[(int64_t)(y0 + r) * aw + x0 + lane];
-                tr[r] = res[(int64_t)(y0 + r) * rw + x0 + lane];
+            for (int k = 0; k < CW; k++) {
+                ta[k] = avg[(int64_t)(y0 + k * RPI + lr) * aw + x0 + lc];
+                tr[k] = res[(int64_t)(y0 + k * RPI + lr) * rw + x0 + lc];
             }
 #pragma unroll
-            for (int r = 0; r < 64; r++) {
-                sA[r * 65 + lane] = ta[r];
-                sR[r * 65 + lane] = tr[r];
+            for (int k = 0; k < CW; k++) {
+                sA[(k * RPI + lr) * LDW + lc] = ta[k];
+                sR[(k * RPI + lr) * LDW + lc] = tr[k];
             }
         } else {
-            for (int r = 0; r < rows; r++) {
-                if (lane < cols) {
-                    sA[r * 65 + lane] = avg[(int64_t)(y0 + r) * aw + x0 + lane];
-                    sR[r * 65 + lane] = res[(int64_t)(y0 + r) * rw + x0 + lane];
+            for (int r = lr; r < rows; r += RPI) {
+                if (lc < cols) {
+                    sA[r * LDW + lc] = avg[(int64_t)(y0 + r) * aw + x0 + lc];
+                    sR[r * LDW + lc] = res[(int64_t)(y0 + r) * rw + x0 + lc];
                 }
             }
         }
@@ -309,19 +313,19 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
             const int64_t rowA = (int64_t)(y0 + lane) * aw;
             const bool has_next = x0 + cols < aw;  // avg[x0 + cols]: first avg of the next chunk or the odd tail
             const int32_t a_next_chunk = has_next ? avg[rowA + x0 + cols] : 0;
-            int32_t* pa = sA + lane * 65;
-            int32_t* pr = sR + lane * 65;
+            int32_t* pa = sA + lane * LDW;
+            int32_t* pr = sR + lane * LDW;
             constexpr int U = 8;  // columns per step: LDS reads and the a-independent part of tendency() run ahead
-            if (cols == 64) {
+            if (cols == CW) {
                 // full chunk: straight-line code, no per-column guards on the serial chain
-                for (int i0 = 0; i0 < 64; i0 += U) {
+                for (int i0 = 0; i0 < CW; i0 += U) {
                     int32_t va[U + 1], vr[U];
                     TendPre tp[U];
 #pragma unroll
-                    for (int j = 0; j <= U; j++) va[j] = pa[i0 + j];  // column 64 of the padded row is scratch
+                    for (int j = 0; j <= U; j++) va[j] = pa[i0 + j];  // column CW of the padded row is scratch
 #pragma unroll
                     for (int j = 0; j < U; j++) vr[j] = pr[i0 + j];
-                    if (i0 + U == 64) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
+                    if (i0 + U == CW) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
 #pragma unroll
                     for (int j = 0; j < U; j++) tp[j] = tend_pre(va[j], va[j + 1]);
                     int32_t o1[U], o2[U];
@@ -359,9 +363,9 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
                     int32_t va[U + 1], vr[U];
                     TendPre tp[U];
 #pragma unroll
-                    for (int j = 0; j <= U; j++) va[j] = pa[min(i0 + j, 64)];
+                    for (int j = 0; j <= U; j++) va[j] = pa[min(i0 + j, CW)];
 #pragma unroll
-                    for (int j = 0; j < U; j++) vr[j] = pr[min(i0 + j, 63)];
+                    for (int j = 0; j < U; j++) vr[j] = pr[min(i0 + j, CW - 1)];
 #pragma unroll
                     for (int j = 0; j < U; j++) {
                         const int i = i0 + j;
@@ -390,9 +394,8 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
         } else {
             for (int r = 0; r < rows; r++) {
                 const int64_t ro = (int64_t)(y0 + r) * ow + 2 * x0;
-                const int j0 = lane, j1 = lane + 64;
-                if (j0 < 2 * cols) out[ro + j0] = (j0 & 1) ? sR[r * 65 + (j0 >> 1)] : sA[r * 65 + (j0 >> 1)];
-                if (j1 < 2 * cols) out[ro + j1] = (j1 & 1) ? sR[r * 65 + (j1 >> 1)] : sA[r * 65 + (j1 >> 1)];
+                const int j0 = lane;  // 2 * CW = 64 outputs per row
+                if (j0 < 2 * cols) out[ro + j0] = (j0 & 1) ? sR[r * LDW + (j0 >> 1)] : sA[r * LDW + (j0 >> 1)];
             }
         }
         x0 += cols;
