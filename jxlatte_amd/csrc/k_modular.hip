@@ -274,9 +274,10 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
     const int32_t* __restrict__ avg = d.a;
     const int32_t* __restrict__ res = d.b;
     int32_t* __restrict__ out = d.o;
-    // 64 rows x CW pairs per LDS chunk. CW = 32 (17 KB per wave, 9 waves per CU) instead of 64 (33 KB, 4 waves per CU):
+    // 64 rows x CW pairs per LDS chunk. CW = 16 (8.7 KB per wave, 18 waves per CU) instead of 64 (33 KB, 4 waves per CU):
     // the segmented walk has thousands of waves per step, and the LDS chunk was what kept all but 4 per CU waiting
-    constexpr int CW = 32, LDW = CW + 1, RPI = 64 / CW;  // row stride; rows covered by one wave-wide load
+    // (8K image: 1.47 ms with 64, 0.97 ms with 32, 0.84 ms with 16)
+    constexpr int CW = 16, LDW = CW + 1, RPI = 64 / CW;  // row stride; rows covered by one wave-wide load
     __shared__ int32_t sA[64 * LDW];  // avg chunk [row][col]; overwritten in place by the even outputs
     __shared__ int32_t sR[64 * LDW];  // res chunk [row][col]; overwritten in place by the odd outputs
     const int lc = threadIdx.x % CW, lr = threadIdx.x / CW;
@@ -316,16 +317,16 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
             int32_t* pa = sA + lane * LDW;
             int32_t* pr = sR + lane * LDW;
             constexpr int U = 8;  // columns per step: LDS reads and the a-independent part of tendency() run ahead
-            if (cols == CW) {
-                // full chunk: straight-line code, no per-column guards on the serial chain
-                for (int i0 = 0; i0 < CW; i0 += U) {
+            if ((cols & (U - 1)) == 0) {
+                // whole steps (full chunks and the warm-up chunk): straight-line code, no per-column guards on the chain
+                for (int i0 = 0; i0 < cols; i0 += U) {
                     int32_t va[U + 1], vr[U];
                     TendPre tp[U];
 #pragma unroll
-                    for (int j = 0; j <= U; j++) va[j] = pa[i0 + j];  // column CW of the padded row is scratch
+                    for (int j = 0; j <= U; j++) va[j] = pa[i0 + j];  // column `cols` is stale or padding: replaced below
 #pragma unroll
                     for (int j = 0; j < U; j++) vr[j] = pr[i0 + j];
-                    if (i0 + U == CW) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
+                    if (i0 + U == cols) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
 #pragma unroll
                     for (int j = 0; j < U; j++) tp[j] = tend_pre(va[j], va[j + 1]);
                     int32_t o1[U], o2[U];
@@ -392,9 +393,10 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
         if (warm) {
             if (lane < rows) d.side[(int64_t)s * h + y0 + lane] = left;  // the state this wave starts its own segment from
         } else {
-            for (int r = 0; r < rows; r++) {
+            constexpr int OPR = 2 * CW, RPW = 64 / OPR;  // outputs per row of the chunk; rows one wave-wide store covers
+            const int j0 = lane % OPR;
+            for (int r = lane / OPR; r < rows; r += RPW) {
                 const int64_t ro = (int64_t)(y0 + r) * ow + 2 * x0;
-                const int j0 = lane;  // 2 * CW = 64 outputs per row
                 if (j0 < 2 * cols) out[ro + j0] = (j0 & 1) ? sR[r * LDW + (j0 >> 1)] : sA[r * LDW + (j0 >> 1)];
             }
         }
