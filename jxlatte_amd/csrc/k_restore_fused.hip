@@ -26,6 +26,10 @@
 
 namespace jxl {
 
+#ifndef JXL_EPF3_PH2_WAVES
+#define JXL_EPF3_PH2_WAVES 2
+#endif
+
 namespace {
 
 __device__ __forceinline__ int mirror_c(int c, int size) {
@@ -449,7 +453,9 @@ struct OutSink {
 // PLAIN = true: float planes out, no transfer function (keeps the double-precision pow() code of the
 // PQ/sRGB transfer out of the hot variant)
 template <bool GAB, int ITERS, bool PLAIN, int PH>
-__global__ __launch_bounds__(512 / PH, PH == 1 ? 8 : 4) void k_restore_fused(const FusedArgs a) {
+// occupancy floor: 8 waves per SIMD (64 VGPRs); the 3-iteration variant holds 48 tap distances per patch and spilled 130
+// VGPRs at that bound, so it is allowed 128 registers (4 waves per SIMD; its 43 KB tile allows 3 workgroups per CU anyway)
+__global__ __launch_bounds__(512 / PH, ITERS == 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_WAVES) : PH == 1 ? 8 : 4) void k_restore_fused(const FusedArgs a) {
     using G = Geo<GAB, ITERS>;
     constexpr int NTHR = 512 / PH;
     extern __shared__ float lds[];
@@ -635,10 +641,11 @@ void launch_tph(const FusedArgs& a, hipStream_t s) {
 }
 template <bool GAB, int ITERS, bool PLAIN>
 void launch_tp(const FusedArgs& a, hipStream_t s) {
-    // iteration 0 (13 taps) keeps the 4x2 patch / 256 threads; the common configurations run 4x1 patches on
-    // 512 threads: twice the waves per CU for the same LDS footprint
+    // 4x1 patches on 512 threads everywhere: twice the waves per CU of 4x2 patches for the same LDS footprint. The
+    // 3-iteration variant used to run 4x2 patches (fewer tap loads for its 13-tap first iteration) but spilled 169 VGPRs
+    // there: 841 us per 4K frame against 259 us with 4x1 patches and a 128-register budget (JXL_RESTORE_PH=2 selects 4x2)
     static const int ph_env = getenv("JXL_RESTORE_PH") ? atoi(getenv("JXL_RESTORE_PH")) : 0;
-    if (ITERS == 3 || ph_env == 2) launch_tph<GAB, ITERS, PLAIN, 2>(a, s);
+    if (ph_env == 2) launch_tph<GAB, ITERS, PLAIN, 2>(a, s);
     else launch_tph<GAB, ITERS, PLAIN, 1>(a, s);
 }
 
