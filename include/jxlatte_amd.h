@@ -189,6 +189,13 @@ jxl_status jxl_vardct_put_group(jxl_ctx* ctx, int32_t pass, int32_t group,
 /* Launch every enabled stage on the ctx stream; inputs are resident after put_group.
  * Asynchronous: returns after enqueue. Re-runnable (inputs are not consumed). */
 jxl_status jxl_vardct_run(jxl_ctx* ctx);
+/* Run n independent frames (one context each, all on one device; every context prepared exactly as for jxl_vardct_run).
+ * The reference decodes its frames one after the other (JXLCodestreamDecoder.decode, :506-720); this entry is what a
+ * batched caller (BASELINE config 5: 8 frames per GPU) uses instead of n jxl_vardct_run calls: the inverse-transform stage
+ * of all frames is enqueued as one launch per kernel class, the remaining stages per frame on the frames' own streams.
+ * Same results, same completion rule (synchronise / read each context as usual). Frames the shared launches do not cover
+ * are run one by one. */
+jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n);
 /* run + synchronize + copy result planes to the host. out[c]: width*height elements of
  * float (JXL_OUT_F32) / uint16 / uint8, row stride = out_stride elements. */
 jxl_status jxl_vardct_finish_frame(jxl_ctx* ctx, void* const out[3], int64_t out_stride);

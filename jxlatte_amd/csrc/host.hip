@@ -99,6 +99,13 @@ struct jxl_ctx {
     int result_elem = 4;
     bool result_interleaved = false;
     int last_launches = 0;
+    uint64_t tables_gen = 0;  // bumped whenever finalize_tables rebuilds the binned work (batch argument cache key)
+    // jxl_vardct_run_batch state (kept by the first context of a batch)
+    DevBuf batch_args;
+    std::vector<std::pair<const jxl_ctx*, uint64_t>> batch_key;
+    struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };  // cls 3 = the special 8x8 kernel
+    std::vector<BatchLaunch> batch_launches;
+    hipEvent_t batch_ev = nullptr;
     bool timing = false;
     static constexpr int kEvSlots = 32;
     hipEvent_t ev[kEvSlots][3] = {};  // ring of (start, after IDCT stage, end) per run
@@ -342,6 +349,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
     c->tables_dirty = false;
+    c->tables_gen++;
     return JXL_OK;
 }
 
@@ -474,6 +482,8 @@ void jxl_ctx_destroy(jxl_ctx* c) {
         for (int j = 0; j < 3; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
+    c->batch_args.release();
     for (int i = 0; i < jxl_ctx::kAux; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
         if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]);
@@ -737,7 +747,11 @@ jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* c, int32_t on) {
     return JXL_OK;
 }
 
-jxl_status jxl_vardct_run(jxl_ctx* c) {
+}  // extern "C"
+
+namespace {
+// the frame pipeline; idct_done: the IDCT stage of this frame has already been enqueued (batched launch)
+jxl_status run_frame(jxl_ctx* c, bool idct_done) {
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
@@ -750,7 +764,7 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
     float* B[3] = {c->planeB[0].as<float>(), c->planeB[1].as<float>(), c->planeB[2].as<float>()};
     hipEvent_t* evs = c->ev[c->ev_runs % jxl_ctx::kEvSlots];
     if (c->timing) (void)hipEventRecord(evs[0], s);
-    if (p.stages & JXL_STAGE_IDCT) {
+    if ((p.stages & JXL_STAGE_IDCT) && !idct_done) {
         DevFrame f;
         fill_dev_frame(c, f);
         const DevBlock* blocks = c->blocks.as<DevBlock>();
@@ -906,6 +920,128 @@ jxl_status jxl_vardct_run(jxl_ctx* c) {
     c->last_launches = launches;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+
+// frames whose IDCT stage can share launches: plain 4:4:4 frames made of the merged-launch types
+bool batchable(const jxl_ctx* c) {
+    return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && (c->p.stages & JXL_STAGE_IDCT);
+}
+}  // namespace
+
+extern "C" {
+
+jxl_status jxl_vardct_run(jxl_ctx* c) { return run_frame(c, false); }
+
+// A batch of independent frames (one context each, all on one device): the IDCT stage of the whole batch runs as ONE
+// launch per register class (k_idct_multi_batch, blockIdx.y = frame), on the first context's stream; every frame's
+// restoration kernel then runs on its own stream as in jxl_vardct_run. Per-frame argument blocks live in device memory
+// and are rebuilt only when a frame's binned work changed. Frames the batched kernels do not cover (chroma subsampling,
+// 128/256-edge varblocks) make the call fall back to n plain runs. Results are those of n jxl_vardct_run calls.
+jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
+    if (!ctxs || n <= 0) return fail(nullptr, JXL_ERR_INVALID_ARGUMENT, "run_batch: no contexts");
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i]) return fail(nullptr, JXL_ERR_INVALID_ARGUMENT, "run_batch: null context %d", i);
+    jxl_ctx* c0 = ctxs[0];
+    bool ok = n > 1 && !getenv("JXL_NO_BATCH");
+    for (int i = 0; i < n && ok; i++) {
+        jxl_ctx* c = ctxs[i];
+        if (c->device != c0->device) return fail(c, JXL_ERR_INVALID_ARGUMENT, "run_batch: contexts on different devices");
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == c) return fail(c, JXL_ERR_INVALID_ARGUMENT, "run_batch: context %d listed twice", i);
+        jxl_status st = bind(c);
+        if (st) return st;
+        if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+        st = finalize_tables(c);
+        if (st) return st;
+        ok = batchable(c);
+    }
+    if (!ok) {
+        for (int i = 0; i < n; i++) {
+            const jxl_status st = run_frame(ctxs[i], false);
+            if (st) return st;
+        }
+        return JXL_OK;
+    }
+    // ---- argument blocks (cached per batch composition)
+    bool same = (int)c0->batch_key.size() == n;
+    for (int i = 0; i < n && same; i++) same = c0->batch_key[i].first == ctxs[i] && c0->batch_key[i].second == ctxs[i]->tables_gen;
+    if (!same) {
+        std::vector<MultiArgs> host_args;
+        c0->batch_launches.clear();
+        for (int cls : {1, 2, 0, 3}) {  // launch order of jxl_vardct_run: heaviest class first, the special kernel last
+            jxl_ctx::BatchLaunch bl{cls, 0, 0, 0, host_args.size() * sizeof(MultiArgs)};
+            for (int i = 0; i < n; i++) {
+                jxl_ctx* c = ctxs[i];
+                DevFrame f;
+                fill_dev_frame(c, f);
+                float* A[3] = {c->planeA[0].as<float>(), c->planeA[1].as<float>(), c->planeA[2].as<float>()};
+                MultiArgs a{};
+                if (cls == 3) {
+                    if (c->special_launches.empty()) continue;
+                    const auto& sl = c->special_launches[0];
+                    a.f = f;
+                    a.blocks = c->blocks.as<DevBlock>();
+                    a.items = c->items.as<WorkItem>() + sl.items_off;
+                    a.seg_n[0] = sl.n_items;
+                    a.o0 = A[0]; a.o1 = A[1]; a.o2 = A[2];
+                    bl.grid_x = std::max(bl.grid_x, sl.n_items);
+                } else {
+                    const jxl_ctx::TypeLaunch* tl = nullptr;
+                    for (const auto& t : c->type_launches)
+                        if (t.cls == cls) tl = &t;
+                    if (!tl) continue;
+                    size_t lds = 0;
+                    const int g = build_idct_multi_args(f, c->blocks.as<DevBlock>(), tl->segs.data(), (int)tl->segs.size(), 3, 0, A, a, &lds);
+                    if (g <= 0) continue;
+                    bl.grid_x = std::max(bl.grid_x, g);
+                    bl.lds_bytes = std::max(bl.lds_bytes, lds);
+                }
+                host_args.push_back(a);
+                bl.n_frames++;
+            }
+            if (bl.n_frames > 0) c0->batch_launches.push_back(bl);
+        }
+        HIP_TRY(c0, hipSetDevice(c0->device));
+        if (!c0->batch_args.ensure(std::max<size_t>(sizeof(MultiArgs), host_args.size() * sizeof(MultiArgs))))
+            return fail(c0, JXL_ERR_OOM, "device allocation failed (batch arguments)");
+        HIP_TRY(c0, hipStreamSynchronize(c0->stream));  // an earlier batch may still be reading the old blocks
+        if (!host_args.empty())
+            HIP_TRY(c0, hipMemcpy(c0->batch_args.p, host_args.data(), host_args.size() * sizeof(MultiArgs), hipMemcpyHostToDevice));
+        c0->batch_key.clear();
+        for (int i = 0; i < n; i++) c0->batch_key.emplace_back(ctxs[i], ctxs[i]->tables_gen);
+        if (!c0->batch_ev) HIP_TRY(c0, hipEventCreateWithFlags(&c0->batch_ev, hipEventDisableTiming));
+    }
+    // ---- the batched IDCT stage on the first context's streams, ordered after whatever the frames' own streams still run
+    hipStream_t s0 = c0->stream;
+    for (int i = 1; i < n; i++) {
+        (void)hipEventRecord(ctxs[i]->fork_ev, ctxs[i]->stream);
+        (void)hipStreamWaitEvent(s0, ctxs[i]->fork_ev, 0);
+    }
+    const bool fork = c0->n_aux > 0 && c0->batch_launches.size() > 1;
+    if (fork) {
+        (void)hipEventRecord(c0->fork_ev, s0);
+        (void)hipStreamWaitEvent(c0->aux[0], c0->fork_ev, 0);
+    }
+    int k = 0;
+    for (const auto& bl : c0->batch_launches) {
+        hipStream_t s = (fork && (k++ & 1)) ? c0->aux[0] : s0;
+        const MultiArgs* da = reinterpret_cast<const MultiArgs*>(static_cast<const char*>(c0->batch_args.p) + bl.offset);
+        if (bl.cls == 3) launch_idct_special_batch(da, bl.n_frames, bl.grid_x, s);
+        else launch_idct_multi_batch(da, bl.n_frames, bl.grid_x, bl.lds_bytes, bl.cls, s);
+    }
+    if (fork) {
+        (void)hipEventRecord(c0->join_ev[0], c0->aux[0]);
+        (void)hipStreamWaitEvent(s0, c0->join_ev[0], 0);
+    }
+    (void)hipEventRecord(c0->batch_ev, s0);
+    for (int i = 1; i < n; i++) (void)hipStreamWaitEvent(ctxs[i]->stream, c0->batch_ev, 0);
+    // ---- per frame: everything after the IDCT stage, on the frame's own stream
+    for (int i = 0; i < n; i++) {
+        const jxl_status st = run_frame(ctxs[i], true);
+        if (st) return st;
+        ctxs[i]->last_launches += (i == 0 ? (int)c0->batch_launches.size() : 0);
+    }
     return JXL_OK;
 }
 

@@ -104,6 +104,11 @@ struct IdctSegment { int type, first_block, n_blocks; };
 int idct_class_of(int type);
 void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const IdctSegment* segs, int n_seg, int nch, int ch0,
                        float* const out[3], hipStream_t s);
+int build_idct_multi_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int nch, int ch0,
+                          float* const out[3], MultiArgs& a, size_t* lds_bytes_out);
+// batch of frames: one MultiArgs block per frame in device memory (blockIdx.y); see k_idct_multi_batch
+void launch_idct_multi_batch(const MultiArgs* dev_args, int n_frames, int grid_x, size_t lds_bytes, int cls, hipStream_t s);
+void launch_idct_special_batch(const MultiArgs* dev_args, int n_frames, int max_items, hipStream_t s);
 // the special 8x8-footprint types: items of up to 64 blocks (one per lane)
 void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],
                          hipStream_t s);

@@ -999,9 +999,9 @@ __device__ __forceinline__ void type_body(const MultiArgs& a, int k, int li, flo
 }
 
 template <int CLASS, bool ALLCH>
-__global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi(const MultiArgs a) {
-    extern __shared__ float lds[];
+__device__ __forceinline__ void idct_multi_body(const MultiArgs& a, float* lds) {
     const int b = (int)blockIdx.x;
+    if (b >= a.seg_b0[a.n_seg]) return;  // batched launch: the grid is sized for the frame with the most items
     int k = 0;
     while (k + 1 < a.n_seg && b >= a.seg_b0[k + 1]) k++;
     // XCD-aware item order inside the segment (see k_restore_fused): consecutive workgroup ids go to different XCDs, so
@@ -1038,15 +1038,31 @@ __global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi(const Mu
     }
 }
 
+template <int CLASS, bool ALLCH>
+__global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi(const MultiArgs a) {
+    extern __shared__ float lds[];
+    idct_multi_body<CLASS, ALLCH>(a, lds);
+}
+
+// The same launch for a BATCH of independent frames: blockIdx.y selects the frame's argument block in device memory
+// (read through the constant address space: uniform, invariant, scalar loads -- exactly what the kernel-argument
+// segment gives the single-frame form). One frame's share of a class is a few hundred to a few thousand waves; eight
+// frames' shares in one grid keep all 256 CUs busy through the whole launch instead of 4 queues' worth of small kernels.
+template <int CLASS>
+__global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi_batch(const MultiArgs* __restrict__ args) {
+    extern __shared__ float lds[];
+    typedef const __attribute__((address_space(4))) MultiArgs* cargs;
+    const MultiArgs& a = *(const MultiArgs*)((cargs)args + blockIdx.y);
+    idct_multi_body<CLASS, true>(a, lds);
+}
+
 size_t medium_lds_bytes(int type);
 
 int idct_class_of(int type) { return (type == 18 || type == 19 || type == 20) ? 1 : (type == 4 || type == 6) ? 2 : 0; }
 
-// segs: the class's types in launch order
-void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const IdctSegment* segs, int n_seg, int nch, int ch0,
-                       float* const out[3], hipStream_t s) {
-    if (n_seg <= 0) return;
-    MultiArgs a;
+// segs: the class's types in launch order. Returns the grid size (0: nothing to do).
+int build_idct_multi_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int nch, int ch0,
+                          float* const out[3], MultiArgs& a, size_t* lds_bytes_out) {
     a.f = f;
     a.blocks = blocks;
     a.items = nullptr;
@@ -1071,8 +1087,18 @@ void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const
         b0 += ((n_items + 7) / 8) * 8;
         lds_bytes = std::max(lds_bytes, medium_lds_bytes(segs[i].type));
     }
-    if (a.n_seg == 0) return;
     for (int k = a.n_seg; k <= MultiArgs::kMaxSeg; k++) a.seg_b0[k] = b0;
+    if (lds_bytes_out) *lds_bytes_out = lds_bytes;
+    return a.n_seg == 0 ? 0 : b0;
+}
+
+void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const IdctSegment* segs, int n_seg, int nch, int ch0,
+                       float* const out[3], hipStream_t s) {
+    if (n_seg <= 0) return;
+    MultiArgs a;
+    size_t lds_bytes = 0;
+    const int b0 = build_idct_multi_args(f, blocks, segs, n_seg, nch, ch0, out, a, &lds_bytes);
+    if (b0 <= 0) return;
     const dim3 grid(b0), wg(256);
     if (nch == 3) {
         if (cls == 0) hipLaunchKernelGGL((k_idct_multi<0, true>), grid, wg, lds_bytes, s, a);
@@ -1083,6 +1109,15 @@ void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const
         else if (cls == 2) hipLaunchKernelGGL((k_idct_multi<2, false>), grid, wg, lds_bytes, s, a);
         else hipLaunchKernelGGL((k_idct_multi<1, false>), grid, wg, lds_bytes, s, a);
     }
+}
+
+// n_frames argument blocks at dev_args (device memory), grid_x = the largest frame's grid
+void launch_idct_multi_batch(const MultiArgs* dev_args, int n_frames, int grid_x, size_t lds_bytes, int cls, hipStream_t s) {
+    if (n_frames <= 0 || grid_x <= 0) return;
+    const dim3 grid(grid_x, n_frames), wg(256);
+    if (cls == 0) hipLaunchKernelGGL((k_idct_multi_batch<0>), grid, wg, lds_bytes, s, dev_args);
+    else if (cls == 2) hipLaunchKernelGGL((k_idct_multi_batch<2>), grid, wg, lds_bytes, s, dev_args);
+    else hipLaunchKernelGGL((k_idct_multi_batch<1>), grid, wg, lds_bytes, s, dev_args);
 }
 
 // blocks of one channel that one workgroup (work item) handles
@@ -1100,11 +1135,11 @@ size_t medium_lds_bytes(int type) {
 
 // the nine special 8x8-footprint types (Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3): whole block in
 // registers, so they get their own launch and register budget
-__global__ __launch_bounds__(64) void k_idct_special(const DevFrame f, const DevBlock* __restrict__ blocks,
-                                                     const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+__device__ __forceinline__ void idct_special_body(const DevFrame& f, const DevBlock* __restrict__ blocks, const WorkItem* __restrict__ items,
+                                                  float* o0, float* o1, float* o2) {
     const WorkItem it = items[blockIdx.x];
     if (threadIdx.x >= it.count) return;
-    const DevBlock b = blocks[it.first + threadIdx.x];
+    const DevBlock b = load_block(blocks, (int)it.first + (int)threadIdx.x);
     const int c = (int)(it.type >> 8);  // one channel per item: 3x the waves, a third of the latency
     switch (it.type & 0xffu) {
     case 1: special_block<1>(f, b, c, o0, o1, o2); break;
@@ -1118,6 +1153,24 @@ __global__ __launch_bounds__(64) void k_idct_special(const DevFrame f, const Dev
     case 17: special_block<17>(f, b, c, o0, o1, o2); break;
     default: break;
     }
+}
+
+__global__ __launch_bounds__(64) void k_idct_special(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                     const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    idct_special_body(f, blocks, items, o0, o1, o2);
+}
+
+// batch form: MultiArgs block per frame (f, blocks, items, o0..2; seg_n[0] = number of items)
+__global__ __launch_bounds__(64) void k_idct_special_batch(const MultiArgs* __restrict__ args) {
+    typedef const __attribute__((address_space(4))) MultiArgs* cargs;
+    const MultiArgs& a = *(const MultiArgs*)((cargs)args + blockIdx.y);
+    if ((int)blockIdx.x >= a.seg_n[0]) return;
+    idct_special_body(a.f, a.blocks, a.items, a.o0, a.o1, a.o2);
+}
+
+void launch_idct_special_batch(const MultiArgs* dev_args, int n_frames, int max_items, hipStream_t s) {
+    if (n_frames <= 0 || max_items <= 0) return;
+    hipLaunchKernelGGL(k_idct_special_batch, dim3(max_items, n_frames), dim3(64), 0, s, dev_args);
 }
 
 void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],

@@ -177,6 +177,15 @@ class Frame:
         """enqueue all stages (asynchronous)"""
         self.ctx.call("jxl_vardct_run")
 
+    @staticmethod
+    def runBatch(frames):
+        """enqueue a batch of independent frames (one context each): jxl_vardct_run_batch -- the inverse-transform
+        stage of all frames shares its launches; results equal those of frame.run() on every frame"""
+        from ._lib import check
+        hs = (C.c_void_p * len(frames))(*[f.ctx.h for f in frames])
+        c0 = frames[0].ctx
+        check(c0.h, c0.lib.jxl_vardct_run_batch(hs, len(frames)))
+
     def _out_array(self):
         es = self.ctx.lib.jxl_vardct_out_elem_size(self.ctx.h)
         p = self.params

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_bits_equal
-from jxlatte_amd import abi, host, synth
+from jxlatte_amd import _lib, abi, host, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -104,3 +104,36 @@ def test_chroma_subsampled_lfquant_and_errors(ctx, orc):
     g2["lf"] = [np.ascontiguousarray(a.astype(np.float32) * np.float32(1.0 / 64)) for a in q]
     fr2["lfgroups"] = [g2]
     assert_bits_equal(got, orc.vardct_frame(fr2, stages=abi.STAGE_IDCT), "subsampled LF quant")
+
+
+def test_run_batch_equals_single_runs(orc):
+    """jxl_vardct_run_batch: frames of different sizes, mixes and restoration settings in one batch, twice (argument
+    blocks cached on the second call), then with one frame replaced (cache rebuilt); every frame equals the oracle"""
+    specs = [dict(w=256, h=128, seed=21, mix="all"), dict(w=512, h=256, seed=22, mix="default"), dict(w=136, h=72, seed=23, mix="dct8"),
+             dict(w=320, h=192, seed=24, mix="default", epf_iters=1)]
+    ctxs = [_lib.Context(0) for _ in specs]
+    try:
+        synths = [synth.make_vardct_frame(sp["w"], sp["h"], seed=sp["seed"], mix=sp["mix"], epf_iters=sp.get("epf_iters", 2)) for sp in specs]
+        frames = [host.Frame.from_synth(c, f) for c, f in zip(ctxs, synths)]
+        exp = [orc.vardct_frame(f) for f in synths]
+        for _ in range(2):
+            host.Frame.runBatch(frames)
+            for i, fr in enumerate(frames):
+                assert_bits_equal(fr.readOutput(), exp[i], "batch frame %d" % i)
+        # a new frame in context 1 (same context, new tables): the cached argument blocks must not be reused
+        synths[1] = synth.make_vardct_frame(384, 128, seed=29, mix="all")
+        frames[1] = host.Frame.from_synth(ctxs[1], synths[1])
+        exp[1] = orc.vardct_frame(synths[1])
+        host.Frame.runBatch(frames)
+        for i, fr in enumerate(frames):
+            assert_bits_equal(fr.readOutput(), exp[i], "batch frame %d after replacement" % i)
+        # a batch holding a frame the shared launches do not cover (128-edge blocks) falls back to single runs
+        synths[2] = synth.make_vardct_frame(512, 256, seed=31, mix="large")
+        frames[2] = host.Frame.from_synth(ctxs[2], synths[2])
+        exp[2] = orc.vardct_frame(synths[2])
+        host.Frame.runBatch(frames)
+        for i, fr in enumerate(frames):
+            assert_bits_equal(fr.readOutput(), exp[i], "fallback batch frame %d" % i)
+    finally:
+        for c in ctxs:
+            c.close()
