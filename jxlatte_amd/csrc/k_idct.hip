@@ -918,7 +918,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(H)) + kc * (KC / 2));
             MirrorAcc<KC> acc;
             acc.init(src[0]);
-#pragma unroll 2
+#pragma unroll 4
             for (int n = 1; n < H; n += 2) {
                 acc.template step<true>(src[n * LD], lut + (n - 1) * H);
                 if (n + 1 < H) acc.template step<false>(src[(n + 1) * LD], lut + n * H);
@@ -943,7 +943,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(W)) + kc * (KC / 2));
             MirrorAcc<KC> acc;
             acc.init(row[0]);
-#pragma unroll 2
+#pragma unroll 4
             for (int n = 1; n < W; n += 2) {
                 acc.template step<true>(row[n], lut + (n - 1) * W);
                 if (n + 1 < W) acc.template step<false>(row[n + 1], lut + n * W);
