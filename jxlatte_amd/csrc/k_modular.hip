@@ -13,6 +13,7 @@
 //   H step: lane = row. A wave owns 64 rows; 64-column chunks of avg/res are staged through LDS so
 //           that global traffic stays row-contiguous while each lane walks its own row.
 #include "jxl_internal.h"
+#include <cstdlib>
 
 namespace jxl {
 
@@ -112,9 +113,16 @@ __device__ __forceinline__ int32_t tend_fast_apply(int32_t a, const TendFast& t,
 // inverseVerticalSqueeze (ModularChannel.java:389-413): lane = column. The avg/res rows do not depend on the
 // recurrence, so they are fetched RV rows ahead (all loads of a chunk in flight) and only the short
 // left -> tendency -> diff -> first/second chain is serial.
-__global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
+// HZ = false: inverseVerticalSqueeze, lane = column, element (k, lane) at [k * w + lane] (every access a coalesced row segment).
+// HZ = true: inverseHorizontalSqueeze walked the same way, lane = row, element (lane, k) at [lane * pitch + k]: a wave's
+// access touches 64 lines, but every lane then reads its own line to the end (L1 / L2 hits), no LDS transposition, no
+// workgroup barriers, nothing but registers -- the form k_inv_hsqueeze (LDS-staged) is compared against in DESIGN.md 4.3.
+template <bool HZ>
+__global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) {
     const SqueezeDesc d = bt.d[blockIdx.y];
-    const int w = d.other, ah = d.adim, rh = d.rdim;
+    const int w = d.other, ah = d.adim, rh = d.rdim;  // w: number of lanes (columns for V, rows for H)
+    // strides of the walked index k and of the lane index, per array
+    const int64_t ak = HZ ? 1 : w, al = HZ ? ah : 1, rk = HZ ? 1 : w, rl = HZ ? rh : 1, ok = HZ ? 1 : w, ol = HZ ? ah + rh : 1;
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
     // segment of pair rows [yb, ye) stored by this wave; the walk starts kSqueezeWarm pairs earlier (jxl_internal.h)
@@ -124,13 +132,13 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
     const int yb = s * kSqueezeSeg;
     const int ye = nseg == 1 ? rh : min(rh, yb + kSqueezeSeg);
     const int ys = s > 0 ? yb - kSqueezeWarm : 0;
-    const int32_t* __restrict__ avg = d.a;
-    const int32_t* __restrict__ res = d.b;
-    int32_t* __restrict__ out = d.o;
+    const int32_t* __restrict__ avg = d.a + (int64_t)x * al;
+    const int32_t* __restrict__ res = d.b + (int64_t)x * rl;
+    int32_t* __restrict__ out = d.o + (int64_t)x * ol;
     constexpr int RV = 8;
     static_assert(kSqueezeWarm % RV == 0 && kSqueezeSeg % RV == 0, "segment and warm-up boundaries fall on chunk boundaries");
     int32_t top = 0;
-    int32_t a = rh > 0 ? avg[(int64_t)ys * w + x] : 0;
+    int32_t a = rh > 0 ? avg[(int64_t)ys * ak] : 0;
     // software pipeline: the loads of chunk k+1 are issued before the serial chain of chunk k runs, so a lone wave
     // does not sit in s_waitcnt for a full memory round trip per chunk
     int32_t rr_n[RV], na_n[RV];
@@ -138,8 +146,8 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
 #pragma unroll
         for (int i = 0; i < RV; i++) {
             const int y = yb_ + i;
-            r_[i] = y < rh ? res[(int64_t)y * w + x] : 0;
-            n_[i] = (y < rh && y + 1 < ah) ? avg[(int64_t)(y + 1) * w + x] : 0;
+            r_[i] = y < rh ? res[(int64_t)y * rk] : 0;
+            n_[i] = (y < rh && y + 1 < ah) ? avg[(int64_t)(y + 1) * ak] : 0;
         }
     };
     fetch(ys, rr_n, na_n);
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
             if (keep) {
 #pragma unroll
                 for (int i = 0; i < RV; i++) {
-                    out[(int64_t)(2 * (y0 + i)) * w + x] = o1[i];
-                    out[(int64_t)(2 * (y0 + i) + 1) * w + x] = o2[i];
+                    out[(int64_t)(2 * (y0 + i)) * ok] = o1[i];
+                    out[(int64_t)(2 * (y0 + i) + 1) * ok] = o2[i];
                 }
             }
             a = av[RV];
@@ -207,8 +215,8 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
                     const int32_t first = wadd(av[i], diff / 2);
                     const int32_t second = wsub(first, diff);
                     if (keep) {
-                        out[(int64_t)(2 * y) * w + x] = first;
-                        out[(int64_t)(2 * y + 1) * w + x] = second;
+                        out[(int64_t)(2 * y) * ok] = first;
+                        out[(int64_t)(2 * y + 1) * ok] = second;
                     }
                     top = second;
                     a = av[i + 1];
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(64) void k_inv_vsqueeze(const SqueezeBatch bt) {
             }
         }
     }
-    if (s == 0 && ah > rh) out[(int64_t)(2 * rh) * w + x] = avg[(int64_t)rh * w + x];
+    if (s == 0 && ah > rh) out[(int64_t)(2 * rh) * ok] = avg[(int64_t)rh * ak];
 }
 
 // Check of the segmented walk (jxl_internal.h): lane = column (V) or row (H). A boundary is good when the state the
@@ -414,8 +422,16 @@ void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s) {
     }
     if (maxdim <= 0) return;
     const dim3 grid((maxdim + 63) / 64, bt.n, nseg);
-    if (bt.horizontal) hipLaunchKernelGGL(k_inv_hsqueeze, grid, dim3(64), 0, s, bt);
-    else hipLaunchKernelGGL(k_inv_vsqueeze, grid, dim3(64), 0, s, bt);
+    // H steps: the register walk (lane = row, strided access) while the step's planes stay cache-resident, the LDS-staged
+    // kernel (coalesced rows) beyond that. JXL_HSQUEEZE_WALK_MAX overrides the threshold (output samples of the step).
+    const char* wm = getenv("JXL_HSQUEEZE_WALK_MAX");  // read per launch: the parity tests force either kernel
+    const int64_t walk_max = wm ? atoll(wm) : (int64_t)8 << 20;  // 8 Mi samples: measured crossover (1080p steps below, 8K steps above)
+    int64_t samples = 0;
+    for (int i = 0; i < bt.n; i++) samples += (int64_t)bt.d[i].other * (bt.d[i].adim + bt.d[i].rdim);
+    const bool h_lds = samples > walk_max;
+    if (bt.horizontal && h_lds) hipLaunchKernelGGL(k_inv_hsqueeze, grid, dim3(64), 0, s, bt);
+    else if (bt.horizontal) hipLaunchKernelGGL(k_inv_squeeze_walk<true>, grid, dim3(64), 0, s, bt);
+    else hipLaunchKernelGGL(k_inv_squeeze_walk<false>, grid, dim3(64), 0, s, bt);
     if (nseg > 1) hipLaunchKernelGGL(k_squeeze_verify, dim3((maxdim + 63) / 64, bt.n), dim3(64), 0, s, bt);
 }
 

@@ -57,7 +57,7 @@ def test_modular_to_float(ctx, orc):
 
 
 @pytest.mark.parametrize("w,h,ch", [(1, 1, 3), (8, 8, 3), (9, 9, 1), (53, 37, 3), (37, 130, 4), (640, 360, 3), (1920, 1080, 3)])
-def test_apply_transforms_default_plan(ctx, orc, w, h, ch):
+def test_apply_transforms_default_plan(ctx, orc, w, h, ch, h_kernel):
     mod = synth.make_modular_frame(w, h, channels=ch, seed=w + h)
     ms = host.ModularStream(ctx, mod["chans"], mod["sp"])
     out = ms.applyTransforms()
@@ -119,9 +119,16 @@ def _one_step(ctx, orc, avg, res, horizontal):
     return out[0], exp[0]
 
 
+@pytest.fixture(params=["walk", "lds"])
+def h_kernel(request, monkeypatch):
+    """both forms of the H step: the register walk and the LDS-staged kernel (the library picks by step size)"""
+    monkeypatch.setenv("JXL_HSQUEEZE_WALK_MAX", "0" if request.param == "lds" else str(1 << 40))
+    return request.param
+
+
 @pytest.mark.parametrize("n,other", [(65, 3), (128, 64), (129, 70), (500, 130), (1000, 5)])
 @pytest.mark.parametrize("horizontal", [True, False])
-def test_segmented_squeeze_random(ctx, orc, n, other, horizontal):
+def test_segmented_squeeze_random(ctx, orc, n, other, horizontal, h_kernel):
     """axis longer than one segment, odd and even totals, ragged last segment, several row / column blocks"""
     rng = np.random.default_rng(n * 7 + other)
     for odd in (0, 1):
@@ -149,7 +156,7 @@ def _adversarial(n, other):
 
 
 @pytest.mark.parametrize("horizontal", [True, False])
-def test_segmented_squeeze_adversarial(ctx, orc, horizontal):
+def test_segmented_squeeze_adversarial(ctx, orc, horizontal, h_kernel):
     a, r = _adversarial(300, 70)
     # the construction does what it says: walking row 0 from the guess at pair 48 never meets the true walk
     t = orc.inv_hsqueeze(a[:1], r[:1])[0]
