@@ -286,9 +286,23 @@ __device__ __forceinline__ void epf_stage(float* buf, int m, const TileCtx& tc, 
     const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
     constexpr int NTHR = 512 / PH;
     const int pcols = (rw + 3) >> 2, prows = (rh + PH - 1) / PH;
+    // thread -> patch. LDS banks are (address / 4) mod 32 for ds_read_b32 / ds_read2 / ds_write, and lanes conflict within a
+    // 32-lane half. A patch is 4 floats wide, so 16 patches of one row put their first words on only 8 banks: the row-major
+    // assignment (lane -> 16 patches x 2 rows) made every tap read and every write-back a 2-way conflict (44 % of all LDS
+    // cycles, profiles/r1). With 8 patches x 4 rows per half the rows add 0, SW, 2 SW, 3 SW: SW is odd, so they land in the
+    // four residue classes mod 4 and the 32 lanes cover the 32 banks exactly once. Any constant tap offset keeps that.
+    const int cblocks = (pcols + 7) >> 3, n_groups = cblocks * ((prows + 3) >> 2);
+    const int q = threadIdx.x & 31;
+    auto patch_of = [&](int g, int& prow, int& pcol) {
+        pcol = (g % cblocks) * 8 + (q & 7);
+        prow = (g / cblocks) * 4 + (q >> 3);
+        return prow < prows && pcol < pcols;
+    };
     if (LAST) {
-        for (int pi = threadIdx.x; pi < pcols * prows; pi += NTHR) {
-            const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
+        for (int g = threadIdx.x >> 5; g < n_groups; g += NTHR / 32) {
+            int prow, pcol;
+            if (!patch_of(g, prow, pcol)) continue;
+            const int ry = m + prow * PH, rx = m + pcol * 4;
             float s_inv[4 * PH], bmul[4 * PH];
             patch_sigma<PH>(ry, rx, tc, sig, scy0, scx0, ep, s_inv, bmul);
             float res[3][4 * PH];
@@ -302,9 +316,9 @@ __device__ __forceinline__ void epf_stage(float* buf, int m, const TileCtx& tc, 
     } else {
         // the largest region any stage sees is the 64x32 window: one patch per thread
         static_assert((64 / 4) * ((32 + PH - 1) / PH) <= NTHR, "one patch per thread");
-        const int pi = threadIdx.x;
-        const bool act = pi < pcols * prows;
-        const int ry = m + (pi / pcols) * PH, rx = m + (pi % pcols) * 4;
+        int prow, pcol;
+        const bool act = patch_of(threadIdx.x >> 5, prow, pcol);  // 16 groups of 8 x 4 patches cover the 16 x 32 window
+        const int ry = m + prow * PH, rx = m + pcol * 4;
         float res[3][4 * PH];
         if (act) {
             float s_inv[4 * PH], bmul[4 * PH];
