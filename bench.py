@@ -241,7 +241,7 @@ def main():
         "kernel_ms_in_batch": round(ms_rest_b, 4),
         "idct_stage_ms": round(ms_idct, 4), "idct_stage_ms_in_batch": round(ms_idct_b, 4), "frame_ms_events": round(ms_all, 4),
         "path_algorithmic_GBps": round(path_gbs, 1), "path_frac": round(path_gbs / HBM_PEAK_GBS, 4),
-        "note": "this kernel is VALU-bound, not HBM-bound: ~430 non-fusable f32 ops/px in the reference's order (DESIGN.md 4.2)",
+        "note": "this kernel is bound by VALU issue and LDS, not HBM: 533 non-fusable f32 instructions per output pixel in the reference's summation order = 73 us at the measured issue peak, 43 us of LDS time, 25 us of HBM time (DESIGN.md 4.2)",
     }
 
     cpu = None

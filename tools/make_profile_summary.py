@@ -76,11 +76,18 @@ traffic = {"kernel": rk, "fetch_KiB": fk, "write_KiB": wk, "launch_us_profiled":
                      "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE as read; per launch, 4K frame, Gab+EPFx2+XYB"}
 json.dump(traffic, open(os.path.join(out_dir, "%s_traffic.json" % tag), "w"), indent=1)
 s = sq[rk]
+lds_s = lds.get(rk, {})
+ISSUE_CYCLES = 2.6  # cycles one wave64 f32 VALU instruction occupies its SIMD with 8 waves per SIMD: tools/ubench/pk_rate.hip
+valu_us = s["SQ_INSTS_VALU"] * ISSUE_CYCLES / 1024 / 2.4e3
 L += ["", "## 3. the dominant kernel", "",
-      "`%s`: %.1f us per launch under the profiler; VALU instructions %.3g per 4K frame = %.0f per output pixel; VALU busy %.3g quad-cycles"
-      % (rk, dur[rk], s["SQ_INSTS_VALU"], s["SQ_INSTS_VALU"] * 64 / (3840 * 2160), s["SQ_ACTIVE_INST_VALU"]),
-      "= %.1f us of pure VALU time at 2.4 GHz over 1024 SIMDs (%.0f %% of the launch). HBM bytes per launch (corrected): %.1f MB vs %.1f MB algorithmic."
-      % (s["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3, 100 * s["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3 / dur[rk], traffic["hbm_bytes_per_launch"] / 1e6,
-         (3840 * 2160 * 24 + 129600 * 8) / 1e6)]
+      "`%s`: %.1f us per launch under the profiler; VALU instructions %.3g per 4K frame = %.0f per output pixel."
+      % (rk, dur[rk], s["SQ_INSTS_VALU"], s["SQ_INSTS_VALU"] * 64 / (3840 * 2160)),
+      "At the measured peak issue rate (%.1f cycles per wave-instruction and SIMD, tools/ubench/pk_rate.hip; packed f32 issues at half that rate,"
+      % ISSUE_CYCLES,
+      "so it buys nothing) that is %.1f us of VALU time over 1024 SIMDs at 2.4 GHz = %.0f %% of the launch. LDS: %.3g active cycles (%.1f us per CU),"
+      % (valu_us, 100 * valu_us / dur[rk], lds_s.get("SQ_LDS_IDX_ACTIVE", 0), lds_s.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / 2.4e3),
+      "%.3g of them bank conflicts. HBM bytes per launch (corrected): %.1f MB vs %.1f MB algorithmic (%.1f us at 8 TB/s)."
+      % (lds_s.get("SQ_LDS_BANK_CONFLICT", 0), traffic["hbm_bytes_per_launch"] / 1e6, (3840 * 2160 * 24 + 129600 * 8) / 1e6,
+         (3840 * 2160 * 24 + 129600 * 8) / 8e6)]
 open(os.path.join(out_dir, "%s_rocprof_summary.md" % tag), "w").write("\n".join(L) + "\n")
 print("\n".join(L[-4:]))
