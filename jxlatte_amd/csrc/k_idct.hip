@@ -13,15 +13,18 @@
 // Three kernel families, all type-uniform per workgroup so there is no divergence:
 //   special : Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3. One LANE per (varblock, channel), the whole
 //             8x8 block lives in VGPRs, every LUT / AFV-basis factor is an instruction literal.
-//   wave    : DCT8, DCT16 and the 16x8 rectangles. One WAVE = 64/max(H,W) blocks of one channel:
+//   wave    : DCT8, DCT16 and the 16x8 rectangles. One WAVE = 64/max(H,W) blocks, their three channels one after
+//             the other (luma first: its dequantised column stays in registers for chroma-from-luma):
 //             lane = one column, coefficient rows streamed from HBM in order (dequantised on the fly),
 //             accumulators in VGPRs, LUT rows wave-uniform (scalar loads); transpose through a
-//             wave-private LDS image; lane = one row for the row pass. No workgroup barriers needed.
+//             wave-private LDS image; lane = one row for the row pass.
 //   wg      : the 32- and 64-point families. One 256-thread workgroup per 64/min(H,W) blocks of one
 //             channel: dequantised coefficients staged in LDS, every 1-D transform split over the
 //             waves (8 or 16 outputs per lane) so that no lane runs a 2x63x64-instruction chain.
 //   large   : 128/256-edge blocks do not fit LDS: dequant -> column pass -> row pass through a
 //             scratch plane, 64x64 register tiles per wave.
+// Launches: one per register class (k_idct_multi<CLASS>: every type of the class in one grid) + the special kernel;
+// k_idct_multi_batch / k_idct_special_batch are the same bodies over a batch of frames (blockIdx.y = frame).
 #include "jxl_internal.h"
 #include "../../include/jxl_tables.h"
 #include <cstdlib>

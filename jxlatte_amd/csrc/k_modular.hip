@@ -8,10 +8,13 @@
 //
 // int32 arithmetic wraps (Java): all adds/muls are done in uint32; `/` truncates toward zero.
 // The squeeze recurrence is serial along the squeeze axis (left = previously OUTPUT odd sample feeds
-// the non-linear tendency()), so parallelism is rows x channels (H) or columns x channels (V).
-//   V step: lane = column, rows walked in order: every load/store is a coalesced row segment.
-//   H step: lane = row. A wave owns 64 rows; 64-column chunks of avg/res are staged through LDS so
-//           that global traffic stays row-contiguous while each lane walks its own row.
+// the non-linear tendency()), so a serial walk has only rows x channels (H) or columns x channels (V) lanes.
+// The axis is therefore cut into 64-pair segments that start 16 pairs early from a guessed state and are
+// verified afterwards (k_squeeze_verify; the scheme and why it is exact: jxl_internal.h, kSqueezeSeg).
+//   V step: k_inv_squeeze_walk<false>, lane = column, rows walked in order: every load/store is a coalesced row segment.
+//   H step: lane = row. Small steps: k_inv_squeeze_walk<true>, the same register-only walk with strided access
+//           (cache-resident planes). Large steps: k_inv_hsqueeze, a wave owns 64 rows and stages 16-pair chunks of
+//           avg/res through LDS so that global traffic stays row-contiguous while each lane walks its own row.
 #include "jxl_internal.h"
 #include <cstdlib>
 

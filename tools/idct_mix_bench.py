@@ -1,4 +1,4 @@
-"""IDCT-stage time (HIP events) for single-type 4K frames: where does k_idct_main spend its time?"""
+"""IDCT-stage time (HIP events) for single-type 4K frames: where does the IDCT stage spend its time? ("DCT8" = a frame of that type only, "DCT8:0.7,DCT32:0.3" = a mix)"""
 import sys, ctypes as C
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
