@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <atomic>
 #include <vector>
 
 using namespace jxl;
@@ -349,7 +350,8 @@ jxl_status finalize_tables(jxl_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
     c->tables_dirty = false;
-    c->tables_gen++;
+    static std::atomic<uint64_t> g_tables_gen{0};  // process-wide: a new context at a recycled address never matches an old key
+    c->tables_gen = ++g_tables_gen;
     return JXL_OK;
 }
 
