@@ -137,3 +137,25 @@ def test_run_batch_equals_single_runs(orc):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("mix,aligned", [("all", True), ("default", True), ("all", False), ("large", True)])
+@pytest.mark.parametrize("nonzero_p", [0.0, 0.004, 0.03])
+def test_sparse_coefficients_and_signed_zero_lf(ctx, orc, mix, aligned, nonzero_p):
+    """Zero skipping in the IDCT MAC loops (MirrorAcc::step_sparse): frames whose coefficient rows / columns are mostly
+    zero, with LF samples that are +0.0, -0.0 (the one start value for which adding a skipped +0 product would matter)
+    and ordinary values mixed, IDCT stage alone and the whole path; bit-identical to the oracle, signs of zeros included"""
+    W, H = (1024, 512) if mix == "large" else (384, 256)
+    frame = synth.make_vardct_frame(W, H, seed=77 + int(nonzero_p * 1000), mix=mix, aligned=aligned, nonzero_p=nonzero_p)
+    rng = np.random.default_rng(5)
+    for g in frame["lfgroups"]:
+        for c in range(3):
+            lf = g["lf"][c]
+            r = rng.random(lf.shape)
+            lf[r < 0.25] = -0.0
+            lf[(r >= 0.25) & (r < 0.45)] = 0.0
+    for stages in (abi.STAGE_IDCT, None):
+        fr = host.Frame.from_synth(ctx, frame, stages=stages)
+        got = fr.decodeFrame()
+        exp = orc.vardct_frame(frame, stages=stages)
+        assert_bits_equal(got, exp, "sparse %s p=%g stages=%s" % (mix, nonzero_p, stages))
