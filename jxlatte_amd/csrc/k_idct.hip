@@ -45,6 +45,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // (measured: 64x64 body 173 -> 330 us).
 typedef const __attribute__((address_space(4))) float* cfloatp;
 typedef const __attribute__((address_space(4))) v2f* cv2fp;
+// Ordering of a wave's own LDS traffic. The wave-level paths transpose through a wave-PRIVATE LDS image: the lanes that read
+// it belong to the wave that wrote it, and the LDS unit executes one wave's instructions in issue order, so no workgroup
+// barrier is needed -- only that the compiler keeps the writes before the reads. A wavefront-scope fence does exactly that
+// and emits no s_barrier: the four waves of a workgroup stop waiting for each other six times per work item.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 __device__ __forceinline__ cfloatp as_const(const float* p) { return (cfloatp)p; }
 // one block record (16 bytes, 16-byte aligned) through the constant address space: s_load_dwordx4 when the index is
 // wave-uniform, global_load_dwordx4 when it is per lane
@@ -669,7 +674,7 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
             for (int k = 0; k < H; k++) dcol[k * LD] = acc.get(k);
         }
     }
-    __syncthreads();  // orders the wave's LDS image for the row pass (all 4 waves run the same sequence)
+    wave_lds_fence();  // the wave's image is complete before its own row pass reads it
     // ---- row pass
     {
         const int bi = lane / H, y = lane % H;
@@ -773,7 +778,7 @@ __device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* 
 #pragma unroll
             for (int k = 0; k < H; k++) dcol[k * LD] = acc.get(k);
         }
-        __syncthreads();  // orders the wave's LDS image for the row pass (all 4 waves run the same sequence)
+        wave_lds_fence();  // the wave's image is complete before its own row pass reads it
         // ---- row pass
         if (bi_row < nb) {
             const float* row = lds + bi_row * IMG + y * LD;
@@ -788,7 +793,7 @@ __device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* 
 #pragma unroll
             for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(o + k) = make_float4(acc.get(k), acc.get(k + 1), acc.get(k + 2), acc.get(k + 3));
         }
-        __syncthreads();  // the image is free for the next channel's column pass
+        wave_lds_fence();  // the row pass has read the image before the next channel's column pass overwrites it
     }
 }
 
