@@ -239,7 +239,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
                 c->h_blocks.insert(c->h_blocks.end(), lists[t].begin(), lists[t].end());
             }
         const uint32_t ch0 = channel < 0 ? 0 : (uint32_t)channel, ch1 = channel < 0 ? 3 : (uint32_t)channel + 1;
-        jxl_ctx::TypeLaunch cl[3] = {{1, channel, {}}, {2, channel, {}}, {0, channel, {}}};  // launch order: heaviest class first
+        jxl_ctx::TypeLaunch cl[2] = {{1, channel, {}}, {0, channel, {}}};  // launch order: heaviest class first
         for (int t : kOrder) {
             if (lists[t].empty()) continue;
             const IdctSegment sg{t, (int)first_of[t], (int)lists[t].size()};
@@ -971,7 +971,7 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
     if (!same) {
         std::vector<MultiArgs> host_args;
         c0->batch_launches.clear();
-        for (int cls : {1, 2, 0, 3}) {  // launch order of jxl_vardct_run: heaviest class first, the special kernel last
+        for (int cls : {1, 0, 3}) {  // launch order of jxl_vardct_run: heaviest class first, the special kernel last
             jxl_ctx::BatchLaunch bl{cls, 0, 0, 0, host_args.size() * sizeof(MultiArgs)};
             for (int i = 0; i < n; i++) {
                 jxl_ctx* c = ctxs[i];

@@ -980,7 +980,9 @@ __host__ __device__ constexpr bool use_wg_path(int h, int w) { return (h > w ? h
 // bodies; a workgroup is type-uniform, so nothing diverges. What makes it work:
 //  (1) classes by register need: class 0 = the types whose body fits 64 VGPRs (8 waves per SIMD; the minimum is part of
 //      __launch_bounds__ so the allocator is held to it -- without it the merged kernel came out at 256 VGPRs + scratch),
-//      class 2 = DCT16 / DCT16x8 (83 VGPRs), class 1 = the 64-point family (LDS-bound at 4 workgroups per CU anyway);
+//      class 1 = the 64-point family together with DCT16 / DCT16x8 (all ~100 VGPRs, 4 waves per SIMD; the 64-point
+//      workgroups are LDS-bound at 4 per CU anyway, and their few hundred long-running waves now share a grid with the
+//      16-point types' thousands instead of holding a queue of their own);
 //  (2) read-only tables through the constant address space (cfloatp, load_block): in a function this large the
 //      compiler no longer proves that the LUT / block records are never clobbered, and uniform loads silently turn
 //      into per-lane vector loads (the 64x64 body went from 173 to 330 us until this was done);
@@ -988,7 +990,7 @@ __host__ __device__ constexpr bool use_wg_path(int h, int w) { return (h > w ? h
 //      the XCD-aware order applied inside each segment;
 //  (4) work items are implicit (segment descriptors in the kernel arguments) and the block record carries hfMultiplier,
 //      so a workgroup's first dependent load is already its coefficients' address.
-// 4K mixed frame: 12 launches -> 4, IDCT stage 156 -> 128 us alone, 134 -> 114 us per frame in a batch of 8.
+// 4K mixed frame: 12 launches -> 3 (+ the restoration kernel).
 // ALLCH (frames without chroma subsampling): a wave-path item is a block group with all three channels (medium_item3);
 // everything else -- the LDS-staged types, and every type of a per-channel launch -- is (block group, channel)
 template <int H, int W, int TYPE, bool ALLCH>
@@ -1030,17 +1032,13 @@ __device__ __forceinline__ void idct_multi_body(const MultiArgs& a, float* lds) 
         case 11: type_body<16, 32, 11, ALLCH>(a, k, li, lds); break;
         default: break;
         }
-    } else if (CLASS == 2) {
-        switch (t) {
-        case 4: type_body<16, 16, 4, ALLCH>(a, k, li, lds); break;
-        case 6: type_body<16, 8, 6, ALLCH>(a, k, li, lds); break;
-        default: break;
-        }
     } else {
         switch (t) {
         case 18: type_body<64, 64, 18, ALLCH>(a, k, li, lds); break;
         case 19: type_body<64, 32, 19, ALLCH>(a, k, li, lds); break;
         case 20: type_body<32, 64, 20, ALLCH>(a, k, li, lds); break;
+        case 4: type_body<16, 16, 4, ALLCH>(a, k, li, lds); break;
+        case 6: type_body<16, 8, 6, ALLCH>(a, k, li, lds); break;
         default: break;
         }
     }
@@ -1066,7 +1064,7 @@ __global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi_batch(co
 
 size_t medium_lds_bytes(int type);
 
-int idct_class_of(int type) { return (type == 18 || type == 19 || type == 20) ? 1 : (type == 4 || type == 6) ? 2 : 0; }
+int idct_class_of(int type) { return (type == 18 || type == 19 || type == 20 || type == 4 || type == 6) ? 1 : 0; }
 
 // segs: the class's types in launch order. Returns the grid size (0: nothing to do).
 int build_idct_multi_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int nch, int ch0,
@@ -1110,11 +1108,9 @@ void launch_idct_multi(const DevFrame& f, const DevBlock* blocks, int cls, const
     const dim3 grid(b0), wg(256);
     if (nch == 3) {
         if (cls == 0) hipLaunchKernelGGL((k_idct_multi<0, true>), grid, wg, lds_bytes, s, a);
-        else if (cls == 2) hipLaunchKernelGGL((k_idct_multi<2, true>), grid, wg, lds_bytes, s, a);
         else hipLaunchKernelGGL((k_idct_multi<1, true>), grid, wg, lds_bytes, s, a);
     } else {
         if (cls == 0) hipLaunchKernelGGL((k_idct_multi<0, false>), grid, wg, lds_bytes, s, a);
-        else if (cls == 2) hipLaunchKernelGGL((k_idct_multi<2, false>), grid, wg, lds_bytes, s, a);
         else hipLaunchKernelGGL((k_idct_multi<1, false>), grid, wg, lds_bytes, s, a);
     }
 }
@@ -1124,7 +1120,6 @@ void launch_idct_multi_batch(const MultiArgs* dev_args, int n_frames, int grid_x
     if (n_frames <= 0 || grid_x <= 0) return;
     const dim3 grid(grid_x, n_frames), wg(256);
     if (cls == 0) hipLaunchKernelGGL((k_idct_multi_batch<0>), grid, wg, lds_bytes, s, dev_args);
-    else if (cls == 2) hipLaunchKernelGGL((k_idct_multi_batch<2>), grid, wg, lds_bytes, s, dev_args);
     else hipLaunchKernelGGL((k_idct_multi_batch<1>), grid, wg, lds_bytes, s, dev_args);
 }
 
