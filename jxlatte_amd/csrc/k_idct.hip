@@ -573,7 +573,7 @@ struct MediumCfg {
     static constexpr int BPW = 64 / MAXD;  // blocks per wave
     static constexpr int LD = W + 1;       // padded row stride
     static constexpr int IMG = H * LD;     // floats per block image
-    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(4 * BPW * IMG + 64);  // 4 waves + qbn/|q| table
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(4 * BPW * IMG + 4 * 64);  // 4 waves, each with its qbn/|q| table
 };
 
 template <int H, int W, int TYPE>
@@ -717,14 +717,16 @@ __device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* 
     float* lds = lds_wg + wave * (Cfg::BPW * IMG);
     const int FW = f.width;
     const float qbn = f.quant_bias_numerator;
-    float* qtab = lds_wg + 4 * Cfg::BPW * IMG;
+    // qbn / |q| table, one per WAVE (64 entries, one division per lane): with the wave-private transposes this leaves the
+    // wave path without a single workgroup barrier -- the four waves of a workgroup never wait for each other
+    float* qtab = lds_wg + 4 * Cfg::BPW * IMG + wave * 64;
     const int bi_col = lane / W, x = lane % W;
     const int bi_row = lane / H, y = lane % H;
     DevBlock b_col{}, b_row{};
     if (bi_col < nb) b_col = load_block(blocks, wfirst + bi_col);
     if (bi_row < nb) b_row = load_block(blocks, wfirst + bi_row);
-    if (wave == 0) qtab[lane] = lane > 0 ? qbn / (float)lane : 0.0f;
-    __syncthreads();
+    qtab[lane] = lane > 0 ? qbn / (float)lane : 0.0f;
+    wave_lds_fence();
     const int py0 = b_col.cy * 8, px0 = b_col.cx * 8;
     const float hfm = (float)b_col.hf_mul;
     const int ty0 = py0 >> 6, tx0 = px0 >> 6;
@@ -1133,7 +1135,7 @@ int medium_blocks_per_wg(int type) {
 size_t medium_lds_bytes(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
     if (use_wg_path(h, w)) return sizeof(float) * (size_t)(2 * medium_blocks_per_wg(type) * h * (w + 1) + 64);
-    return sizeof(float) * (size_t)(medium_blocks_per_wg(type) * h * (w + 1) + 64);
+    return sizeof(float) * (size_t)(medium_blocks_per_wg(type) * h * (w + 1) + 4 * 64);
 }
 
 // the nine special 8x8-footprint types (Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3): whole block in
