@@ -40,6 +40,16 @@ public final class NativeBackend implements AutoCloseable {
     public native void putGroup(int pass, int group, ByteBuffer qX, ByteBuffer qY, ByteBuffer qB, int strideX, int strideY,
         int strideB);                                              // jxl_vardct_put_group
     public native void finishFrame(ByteBuffer outX, ByteBuffer outY, ByteBuffer outB, long stride); // jxl_vardct_finish_frame
+    /** Asynchronous form for independent frames decoded side by side (one NativeBackend each): run() enqueues the frame
+     *  on its context's stream, readOutput() waits for it. runBatch hands several prepared frames to one call. */
+    public native void run();                                      // jxl_vardct_run
+    public native void readOutput(ByteBuffer outX, ByteBuffer outY, ByteBuffer outB, long stride); // jxl_vardct_read_output
+    public static void runBatch(NativeBackend[] frames) {          // jxl_vardct_run_batch
+        long[] h = new long[frames.length];
+        for (int i = 0; i < frames.length; i++) h[i] = frames[i].ctx;
+        runBatch0(h);
+    }
+    private static native void runBatch0(long[] ctxs);
     /** channels: one direct buffer per encoded channel; squeezeParams: 4 ints per step. */
     public native void modularApply(ByteBuffer[] chans, int[] widths, int[] heights, int[] squeezeParams, int rctType,
         int rctBegin, ByteBuffer[] out, int[] outWidths, int[] outHeights); // jxl_modular_apply

@@ -118,6 +118,32 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_finishFrame
     CHECK(jxl_vardct_finish_frame(c, out, stride));
 }
 
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_run(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_vardct_run(c));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
+        jlong stride) {
+    jxl_ctx* c = ctx_of(e, self);
+    void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
+    CHECK(jxl_vardct_read_output(c, out, stride));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_runBatch0(JNIEnv* e, jclass k, jlongArray ctxs) {
+    const jsize n = (*e)->GetArrayLength(e, ctxs);
+    jlong h[64];
+    jxl_ctx* c[64];
+    if (n <= 0 || n > 64) {
+        rethrow(e, NULL, JXL_ERR_INVALID_ARGUMENT);
+        return;
+    }
+    (*e)->GetLongArrayRegion(e, ctxs, 0, n, h);
+    for (jsize i = 0; i < n; i++) c[i] = (jxl_ctx*)(intptr_t)h[i];
+    const jxl_status st = jxl_vardct_run_batch(c, (int32_t)n);
+    if (st != JXL_OK) rethrow(e, c[0], st);
+}
+
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularApply(JNIEnv* e, jobject self, jobjectArray chans, jintArray widths,
         jintArray heights, jintArray squeezeParams, jint rctType, jint rctBegin, jobjectArray out, jintArray outWidths, jintArray outHeights) {
     jxl_ctx* c = ctx_of(e, self);
