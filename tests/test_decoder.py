@@ -178,6 +178,38 @@ def test_white_jxl_is_white(oracle_backend):
     assert px.shape == (240, 320, 3) and px.min() >= 254
 
 
+def test_vardct_decodes_look_like_photographs(oracle_backend):
+    """A semantic pin of the oracle's VarDCT restatement that does not come from the oracle itself: lenna.jxl and bbb.jxl
+    are photographic / rendered pictures, so a correct decode is smooth across the 8x8 varblock grid. A wrong dequantiser,
+    chroma-from-luma, LLF, inverse transform, Gaborish, EPF or XYB leaves block edges, ringing or colour casts that these
+    statistics catch: (1) the mean absolute step across 8-pixel cell borders is no larger than the step inside cells,
+    (2) neighbouring pixels are highly correlated, (3) nearly all samples lie inside the displayable range, (4) the picture
+    is not flat, and (5) the three channels are positively correlated (a luminance picture with chroma, not noise)."""
+    for name in ("lenna", "bbb"):
+        _, img = decode(name, oracle_backend)
+        buf = io.BytesIO()
+        PNGWriter(img).write(buf)
+        px, bd = read_png(buf.getvalue())
+        a = px[..., :3].astype(np.float64) / (255.0 if bd == 8 else 65535.0)
+        g = a.mean(axis=2)
+        dx = np.abs(np.diff(g, axis=1))
+        cols = np.arange(dx.shape[1])
+        on_border = (cols % 8) == 7          # step from column 8k+7 to 8k+8
+        ratio_x = dx[:, on_border].mean() / dx[:, ~on_border].mean()
+        dy = np.abs(np.diff(g, axis=0))
+        rows = np.arange(dy.shape[0])
+        ratio_y = dy[(rows % 8) == 7].mean() / dy[(rows % 8) != 7].mean()
+        assert 0.8 < ratio_x < 1.15 and 0.8 < ratio_y < 1.15, (name, ratio_x, ratio_y)   # no blocking at the cell grid
+        cx = np.corrcoef(g[:, :-1].ravel(), g[:, 1:].ravel())[0, 1]
+        cy = np.corrcoef(g[:-1].ravel(), g[1:].ravel())[0, 1]
+        assert cx > 0.9 and cy > 0.9, (name, cx, cy)
+        assert ((px == 0) | (px == (255 if bd == 8 else 65535))).mean() < 0.25, name     # not clipped away
+        assert g.std() > 0.05, name
+        rg = np.corrcoef(a[..., 0].ravel(), a[..., 1].ravel())[0, 1]
+        gb = np.corrcoef(a[..., 1].ravel(), a[..., 2].ravel())[0, 1]
+        assert rg > 0.5 and gb > 0.5, (name, rg, gb)
+
+
 CRCS = {}
 
 
