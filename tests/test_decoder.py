@@ -210,6 +210,26 @@ def test_vardct_decodes_look_like_photographs(oracle_backend):
         assert rg > 0.5 and gb > 0.5, (name, rg, gb)
 
 
+def test_modular_decodes_are_structured_images(oracle_backend):
+    """Semantic pins of the integer path on the reference's own sample files. patches-lossless.jxl is a lossless screenshot
+    and art.jxl a JXL-art tree: a correct decode has a few hundred distinct colours (326 and 71), while any slip in the
+    predictors, RCT, palette or Squeeze arithmetic smears them into tens of thousands. quilt.jxl (frame-level Squeeze, 16
+    steps), blendmodes_5.jxl and wb-rainbow.jxl are continuous-tone: neighbouring pixels correlate strongly."""
+    def pixels(name):
+        _, img = decode(name, oracle_backend)
+        buf = io.BytesIO()
+        PNGWriter(img).write(buf)
+        return read_png(buf.getvalue())[0]
+    for name, limit in (("patches-lossless", 1000), ("art", 200)):
+        px = pixels(name)
+        assert len(np.unique(px.reshape(-1, px.shape[-1]), axis=0)) < limit, name
+    for name, floor in (("quilt", 0.7), ("blendmodes_5", 0.95), ("wb-rainbow", 0.85)):
+        g = pixels(name)[..., :3].astype(np.float64).mean(axis=2)
+        cx = np.corrcoef(g[:, :-1].ravel(), g[:, 1:].ravel())[0, 1]
+        cy = np.corrcoef(g[:-1].ravel(), g[1:].ravel())[0, 1]
+        assert cx > floor and cy > floor, (name, cx, cy)
+
+
 CRCS = {}
 
 
