@@ -146,6 +146,19 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
     // does not sit in s_waitcnt for a full memory round trip per chunk
     int32_t rr_n[RV], na_n[RV];
     auto fetch = [&](int yb_, int32_t* r_, int32_t* n_) {
+        if (HZ && yb_ + RV < ah && yb_ + RV <= rh) {
+            // the lane's own run of 8 + 8 consecutive samples as four 16-byte loads (4-byte aligned: rows start anywhere):
+            // a quarter of the requests of eight dword loads per array, and each touches the lane's cache line once
+            struct __attribute__((packed, aligned(4))) i4 { int32_t v[4]; };
+            const i4 r0 = *reinterpret_cast<const i4*>(res + yb_), r1 = *reinterpret_cast<const i4*>(res + yb_ + 4);
+            const i4 a0 = *reinterpret_cast<const i4*>(avg + yb_ + 1), a1 = *reinterpret_cast<const i4*>(avg + yb_ + 5);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                r_[i] = r0.v[i]; r_[4 + i] = r1.v[i];
+                n_[i] = a0.v[i]; n_[4 + i] = a1.v[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < RV; i++) {
             const int y = yb_ + i;
@@ -200,7 +213,15 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
                     top = o2[i];
                 }
             }
-            if (keep) {
+            if (keep && HZ) {  // 16 consecutive outputs of the lane's row: four 16-byte stores
+                struct __attribute__((packed, aligned(4))) i4 { int32_t v[4]; };
+#pragma unroll
+                for (int i = 0; i < RV; i += 2) {
+                    i4 t;
+                    t.v[0] = o1[i]; t.v[1] = o2[i]; t.v[2] = o1[i + 1]; t.v[3] = o2[i + 1];
+                    *reinterpret_cast<i4*>(out + 2 * (y0 + i)) = t;
+                }
+            } else if (keep) {
 #pragma unroll
                 for (int i = 0; i < RV; i++) {
                     out[(int64_t)(2 * (y0 + i)) * ok] = o1[i];
