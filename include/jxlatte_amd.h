@@ -194,8 +194,8 @@ jxl_status jxl_vardct_run(jxl_ctx* ctx);
  * batched caller (BASELINE config 5: 8 frames per GPU) uses instead of n jxl_vardct_run calls: the inverse-transform stage
  * of all frames is enqueued as one launch per kernel class, the remaining stages per frame on the frames' own streams.
  * Same results, same completion rule (synchronise / read each context as usual). Frames the shared launches do not cover
- * are run one by one. Measured on MI355X: the faster form for small, launch-bound frames (8 x 1280x720: +21 %, 8 x 512x512:
- * +58 %); for 4K frames n jxl_vardct_run calls on n contexts are 5 % faster. */
+ * are run one by one. Measured on MI355X: the faster form for small, launch-bound frames (8 x 1280x720: +16 %, 8 x 512x512:
+ * +40..70 %); for 4K frames n jxl_vardct_run calls on n contexts are 5 % faster. */
 jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n);
 /* run + synchronize + copy result planes to the host. out[c]: width*height elements of
  * float (JXL_OUT_F32) / uint16 / uint8, row stride = out_stride elements. */

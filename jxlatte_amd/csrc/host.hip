@@ -102,7 +102,9 @@ struct jxl_ctx {
     int last_launches = 0;
     uint64_t tables_gen = 0;  // bumped whenever finalize_tables rebuilds the binned work (batch argument cache key)
     // jxl_vardct_run_batch state (kept by the first context of a batch)
-    DevBuf batch_args;
+    DevBuf batch_args, batch_restore_args;
+    std::vector<FusedArgs> batch_restore_host;
+    bool batch_restore_valid = false;
     std::vector<std::pair<const jxl_ctx*, uint64_t>> batch_key;
     struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };  // cls 3 = the special 8x8 kernel
     std::vector<BatchLaunch> batch_launches;
@@ -486,6 +488,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     c->batch_args.release();
+    c->batch_restore_args.release();
     for (int i = 0; i < jxl_ctx::kAux; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
         if (c->join_ev[i]) (void)hipEventDestroy(c->join_ev[i]);
@@ -752,8 +755,9 @@ jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* c, int32_t on) {
 }  // extern "C"
 
 namespace {
-// the frame pipeline; idct_done: the IDCT stage of this frame has already been enqueued (batched launch)
-jxl_status run_frame(jxl_ctx* c, bool idct_done) {
+// the frame pipeline; idct_done: the IDCT stage of this frame has already been enqueued (batched launch); collect: the
+// fused restoration launch is not enqueued here, its argument block is handed back instead (*collected = true if it was)
+jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, bool* collected = nullptr) {
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
@@ -865,7 +869,12 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done) {
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
         const float* src[3] = {cur[0], cur[1], cur[2]};
-        fused = launch_restore_fused(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, s);
+        if (collect) {
+            fused = fill_restore_fused_args(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, *collect);
+            if (collected) *collected = fused;
+        } else {
+            fused = launch_restore_fused(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, s);
+        }
         if (fused) {
             launches++;
             for (int i = 0; i < 3; i++) c->result[i] = dst[i];
@@ -1012,6 +1021,7 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
             HIP_TRY(c0, hipMemcpy(c0->batch_args.p, host_args.data(), host_args.size() * sizeof(MultiArgs), hipMemcpyHostToDevice));
         c0->batch_key.clear();
         for (int i = 0; i < n; i++) c0->batch_key.emplace_back(ctxs[i], ctxs[i]->tables_gen);
+        c0->batch_restore_valid = false;
         if (!c0->batch_ev) HIP_TRY(c0, hipEventCreateWithFlags(&c0->batch_ev, hipEventDisableTiming));
     }
     // ---- the batched IDCT stage on the first context's streams, ordered after whatever the frames' own streams still run
@@ -1036,9 +1046,37 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
         (void)hipEventRecord(c0->join_ev[0], c0->aux[0]);
         (void)hipStreamWaitEvent(s0, c0->join_ev[0], 0);
     }
+    // ---- the restoration stage: one launch for the whole batch when every frame takes the fused kernel in the same
+    //      variant (Gaborish, EPF iterations, output kind); otherwise per frame, on the frame's own stream
+    static const bool batch_restore = !getenv("JXL_NO_BATCH_RESTORE");
+    std::vector<FusedArgs> fa((size_t)n);
+    bool all = batch_restore;
+    for (int i = 0; i < n; i++) all = all && ctxs[i]->W >= 8 && ctxs[i]->H >= 8;  // what the fused kernel covers: in collect
+    if (all) {                                                                     // mode such a frame enqueues nothing
+        for (int i = 0; i < n && all; i++) {
+            bool got = false;
+            const jxl_status st = run_frame(ctxs[i], true, &fa[(size_t)i], &got);  // bookkeeping + argument block, no launch
+            if (st) return st;
+            all = got && restore_fused_variant(fa[(size_t)i]) == restore_fused_variant(fa[0]);  // !got: no restoration stage enabled
+        }
+    }
+    if (all) {
+        if (!c0->batch_restore_valid || c0->batch_restore_host.size() != (size_t)n ||
+            memcmp(c0->batch_restore_host.data(), fa.data(), sizeof(FusedArgs) * (size_t)n) != 0) {
+            if (!c0->batch_restore_args.ensure(sizeof(FusedArgs) * (size_t)n)) return fail(c0, JXL_ERR_OOM, "device allocation failed (batch arguments)");
+            HIP_TRY(c0, hipStreamSynchronize(s0));  // the previous batch may still be reading the old blocks
+            HIP_TRY(c0, hipMemcpy(c0->batch_restore_args.p, fa.data(), sizeof(FusedArgs) * (size_t)n, hipMemcpyHostToDevice));
+            c0->batch_restore_host = fa;
+            c0->batch_restore_valid = true;
+        }
+        launch_restore_fused_batch(fa.data(), c0->batch_restore_args.as<FusedArgs>(), n, s0);
+        (void)hipEventRecord(c0->batch_ev, s0);
+        for (int i = 1; i < n; i++) (void)hipStreamWaitEvent(ctxs[i]->stream, c0->batch_ev, 0);
+        c0->last_launches += (int)c0->batch_launches.size() + 1;
+        return JXL_OK;
+    }
     (void)hipEventRecord(c0->batch_ev, s0);
     for (int i = 1; i < n; i++) (void)hipStreamWaitEvent(ctxs[i]->stream, c0->batch_ev, 0);
-    // ---- per frame: everything after the IDCT stage, on the frame's own stream
     for (int i = 0; i < n; i++) {
         const jxl_status st = run_frame(ctxs[i], true);
         if (st) return st;

@@ -142,6 +142,20 @@ struct RestoreParams {
     float global_scale_f;
     float sharp_lut[8];
 };
+// argument block of the fused kernel (one per frame; an array of them for the batched launch)
+struct FusedArgs {
+    const float* in[3];
+    void* out[3];
+    const int32_t* hf_mul;
+    const int32_t* sharpness;
+    int W, H, bw;
+    RestoreParams p;
+};
+// false if the configuration is not covered by the fused kernel
+bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
+                             const int32_t* sharpness, const RestoreParams& p, FusedArgs& a);
+int restore_fused_variant(const FusedArgs& a);  // which kernel instantiation the arguments select
+void launch_restore_fused_batch(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s);
 // returns false if the configuration is not covered by the fused kernel (caller falls back to stage kernels)
 bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                           const int32_t* sharpness, const RestoreParams& p, hipStream_t s);

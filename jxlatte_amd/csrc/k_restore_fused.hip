@@ -21,6 +21,7 @@
 // Frame edges: Gab reads clamped coordinates, EPF reads mirrored ones (MathHelper.mirrorCoordinate);
 // edge tiles re-create that by copying mirrored positions inside LDS after each stage.
 #include "jxl_internal.h"
+#include <algorithm>
 #include "jxl_fastpow.h"
 #include <cstdlib>
 
@@ -363,14 +364,6 @@ __device__ __forceinline__ void mirror_fixup(float* __restrict__ buf, int m, int
     }
 }
 
-struct FusedArgs {
-    const float* in[3];
-    void* out[3];
-    const int32_t* hf_mul;
-    const int32_t* sharpness;
-    int W, H, bw;
-    RestoreParams p;
-};
 
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) f2a4 {
@@ -467,9 +460,7 @@ struct OutSink {
 // PLAIN = true: float planes out, no transfer function (keeps the double-precision pow() code of the
 // PQ/sRGB transfer out of the hot variant)
 template <bool GAB, int ITERS, bool PLAIN, int PH>
-// occupancy floor: 8 waves per SIMD (64 VGPRs); the 3-iteration variant holds 48 tap distances per patch and spilled 130
-// VGPRs at that bound, so it is allowed 128 registers (4 waves per SIMD; its 43 KB tile allows 3 workgroups per CU anyway)
-__global__ __launch_bounds__(512 / PH, ITERS == 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_WAVES) : PH == 1 ? 8 : 4) void k_restore_fused(const FusedArgs a) {
+__device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
     using G = Geo<GAB, ITERS>;
     constexpr int NTHR = 512 / PH;
     extern __shared__ float lds[];
@@ -640,6 +631,22 @@ __global__ __launch_bounds__(512 / PH, ITERS == 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_
     }
 }
 
+#define JXL_RESTORE_BOUNDS(ITERS, PH) __launch_bounds__(512 / PH, ITERS == 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_WAVES) : PH == 1 ? 8 : 4)
+// occupancy floor: 8 waves per SIMD (64 VGPRs); the 3-iteration variant holds 48 tap distances per patch and spilled 130
+// VGPRs at that bound, so it is allowed 128 registers (4 waves per SIMD; its 43 KB tile allows 3 workgroups per CU anyway)
+template <bool GAB, int ITERS, bool PLAIN, int PH>
+__global__ JXL_RESTORE_BOUNDS(ITERS, PH) void k_restore_fused(const FusedArgs a) {
+    restore_fused_body<GAB, ITERS, PLAIN, PH>(a);
+}
+
+// a batch of frames in one launch (jxl_vardct_run_batch): blockIdx.y = frame, argument blocks in device memory read
+// through the constant address space (uniform scalar loads, as from the kernel-argument segment)
+template <bool GAB, int ITERS, bool PLAIN>
+__global__ JXL_RESTORE_BOUNDS(ITERS, 1) void k_restore_fused_batch(const FusedArgs* __restrict__ args) {
+    typedef const __attribute__((address_space(4))) FusedArgs* cargs;
+    restore_fused_body<GAB, ITERS, PLAIN, 1>(*(const FusedArgs*)((cargs)args + blockIdx.y));
+}
+
 template <bool GAB, int ITERS, bool PLAIN, int PH>
 void launch_tph(const FusedArgs& a, hipStream_t s) {
     using G = Geo<GAB, ITERS>;
@@ -671,11 +678,10 @@ void launch_t(const FusedArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
-                          const int32_t* sharpness, const RestoreParams& p, hipStream_t s) {
+bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
+                             const int32_t* sharpness, const RestoreParams& p, FusedArgs& a) {
     if (w < 8 || h < 8) return false;  // mirror fix-up assumes at most one reflection within the halo
     if (p.epf_iters > 0 && (!hf_mul || !sharpness)) return false;
-    FusedArgs a;
     for (int c = 0; c < 3; c++) {
         a.in[c] = in[c];
         a.out[c] = out[c];
@@ -686,6 +692,61 @@ bool launch_restore_fused(const float* const in[3], void* const out[3], int h, i
     a.H = h;
     a.bw = (w + 7) >> 3;
     a.p = p;
+    return true;
+}
+
+namespace {
+template <bool GAB, int ITERS, bool PLAIN>
+void launch_batch_t(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s) {
+    using G = Geo<GAB, ITERS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused_batch<GAB, ITERS, PLAIN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        attr_set = true;
+    }
+    int max_tiles = 0;
+    for (int i = 0; i < n; i++)
+        max_tiles = std::max(max_tiles, ((host_args[i].W + G::OW - 1) / G::OW) * ((host_args[i].H + G::OH - 1) / G::OH));
+    const dim3 grid(((max_tiles + 7) / 8) * 8, n);
+    hipLaunchKernelGGL((k_restore_fused_batch<GAB, ITERS, PLAIN>), grid, dim3(512), G::LDS_BYTES, s, dev_args);
+}
+template <bool GAB, int ITERS>
+void launch_batch_i(const FusedArgs* h, const FusedArgs* d, int n, bool plain, hipStream_t s) {
+    if (plain) launch_batch_t<GAB, ITERS, true>(h, d, n, s);
+    else launch_batch_t<GAB, ITERS, false>(h, d, n, s);
+}
+}  // namespace
+
+// the kernel variant a frame's arguments select: Gaborish on/off, EPF iterations, plain float output or transfer / quantise
+int restore_fused_variant(const FusedArgs& a) {
+    const bool plain = a.p.transfer == JXL_TRANSFER_NONE && a.p.max_value == 0;
+    return (a.p.gab ? 8 : 0) | (a.p.epf_iters & 3) << 1 | (plain ? 1 : 0);
+}
+
+// host_args: the n frames' argument blocks (all of one variant), dev_args: the same blocks in device memory
+void launch_restore_fused_batch(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s) {
+    if (n <= 0) return;
+    const int v = restore_fused_variant(host_args[0]);
+    const bool plain = v & 1, gab = (v & 8) != 0;
+    const int it = (v >> 1) & 3;
+    if (gab) {
+        if (it == 0) launch_batch_i<true, 0>(host_args, dev_args, n, plain, s);
+        else if (it == 1) launch_batch_i<true, 1>(host_args, dev_args, n, plain, s);
+        else if (it == 2) launch_batch_i<true, 2>(host_args, dev_args, n, plain, s);
+        else launch_batch_i<true, 3>(host_args, dev_args, n, plain, s);
+    } else {
+        if (it == 0) launch_batch_i<false, 0>(host_args, dev_args, n, plain, s);
+        else if (it == 1) launch_batch_i<false, 1>(host_args, dev_args, n, plain, s);
+        else if (it == 2) launch_batch_i<false, 2>(host_args, dev_args, n, plain, s);
+        else launch_batch_i<false, 3>(host_args, dev_args, n, plain, s);
+    }
+}
+
+bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
+                          const int32_t* sharpness, const RestoreParams& p, hipStream_t s) {
+    FusedArgs a;
+    if (!fill_restore_fused_args(in, out, h, w, hf_mul, sharpness, p, a)) return false;
     const int it = p.epf_iters;
     if (p.gab) {
         if (it == 0) launch_t<true, 0>(a, s);

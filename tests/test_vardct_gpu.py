@@ -127,6 +127,11 @@ def test_run_batch_equals_single_runs(orc):
         host.Frame.runBatch(frames)
         for i, fr in enumerate(frames):
             assert_bits_equal(fr.readOutput(), exp[i], "batch frame %d after replacement" % i)
+        # frames 0..2 share one restoration variant (Gab + EPF x2, float out): the restoration stage is one launch too
+        for _ in range(2):
+            host.Frame.runBatch(frames[:3])
+            for i, fr in enumerate(frames[:3]):
+                assert_bits_equal(fr.readOutput(), exp[i], "same-variant batch frame %d" % i)
         # a batch holding a frame the shared launches do not cover (128-edge blocks) falls back to single runs
         synths[2] = synth.make_vardct_frame(512, 256, seed=31, mix="large")
         frames[2] = host.Frame.from_synth(ctxs[2], synths[2])
