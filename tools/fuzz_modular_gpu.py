@@ -1,0 +1,33 @@
+"""Randomised device-vs-oracle sweep of the Modular path (GPU box): image sizes around the segment / chunk boundaries,
+1-4 channels, residual magnitudes from flat to near the int32 limits, RCT types, both forms of the horizontal step.
+    python tools/fuzz_modular_gpu.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from jxlatte_amd import _lib, host, synth
+from oracle import pyoracle as orc
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+ctx = _lib.Context(0)
+bad = 0
+sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 130, 160, 255, 257, 300, 511, 513, 700]
+for case in range(n_cases):
+    w, h = int(rng.choice(sizes)), int(rng.choice(sizes))
+    ch = int(rng.integers(1, 5))
+    scale = float(rng.choice([0.0, 1.0, 4.0, 300.0, 2e6, 5e8]))
+    os.environ["JXL_HSQUEEZE_WALK_MAX"] = "0" if rng.integers(0, 2) else str(1 << 40)
+    mod = synth.make_modular_frame(w, h, channels=ch, seed=int(rng.integers(1, 1 << 30)), res_scale=max(scale, 1e-9))
+    if scale == 0.0:
+        for a in mod["chans"][ch:]:
+            a[:] = 0
+    rct = int(rng.integers(-1, 42)) if ch >= 3 else -1
+    ms = host.ModularStream(ctx, mod["chans"], mod["sp"], rctType=rct, rctBegin=0)
+    out = ms.applyTransforms()
+    exp = orc.modular_apply(mod["chans"], mod["sp"], rct_type=rct, rct_begin=0)
+    ok = len(out) == len(exp) and all(np.array_equal(a, b) for a, b in zip(out, exp))
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d: %dx%d ch=%d scale=%g rct=%d walk_max=%s" % (case, w, h, ch, scale, rct, os.environ["JXL_HSQUEEZE_WALK_MAX"]))
+print("modular fuzz: %d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
