@@ -53,3 +53,21 @@ def test_lf_only_frame_is_flat_at_8k(ctx):
     out = host.Frame.from_synth(ctx, frame).decodeFrame()
     for c in range(3):
         assert np.abs(out[c] - np.float32(0.25) * (c + 1)).max() < 2e-6
+
+
+def test_8k_modular_segmented_equals_serial_walk(ctx, monkeypatch):
+    """BASELINE's 8K Modular size through a size-independent property: the segmented squeeze, with either form of the
+    horizontal step or the size-dependent mix of both, gives exactly what one serial walk per row / column gives"""
+    mod = synth.make_modular_frame(7680, 4320, channels=3, seed=7)
+    outs = {}
+    for mode, env in (("serial", {"JXL_SQUEEZE_SERIAL": "1"}), ("lds", {"JXL_HSQUEEZE_WALK_MAX": "0"}),
+                      ("hybrid", {}), ("walk", {"JXL_HSQUEEZE_WALK_MAX": str(1 << 40)})):
+        for k in ("JXL_SQUEEZE_SERIAL", "JXL_HSQUEEZE_WALK_MAX"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ms = host.ModularStream(ctx, mod["chans"], mod["sp"])
+        outs[mode] = [np.array(a, copy=True) for a in ms.applyTransforms()]
+    for mode in ("lds", "hybrid", "walk"):
+        for a, b in zip(outs[mode], outs["serial"]):
+            assert a.shape == (4320, 7680) and np.array_equal(a, b), mode
