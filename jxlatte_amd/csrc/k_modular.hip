@@ -179,13 +179,11 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
         if (y0 + RV < ye) fetch(y0 + RV, rr_n, na_n);
         // everything that does not depend on the recurrence first
         int32_t av[RV + 1];
-        TendPre tp[RV];
         av[0] = a;
 #pragma unroll
         for (int i = 0; i < RV; i++) {
             const int y = y0 + i;
             av[i + 1] = y + 1 < ah ? na[i] : av[i];
-            tp[i] = tend_pre(av[i], av[i + 1]);
         }
         if (y0 + RV <= ye) {  // full chunk: no guards on the serial chain, stores after it
             int32_t o1[RV], o2[RV];
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
                 top = top0;
 #pragma unroll
                 for (int i = 0; i < RV; i++) {
-                    const int32_t diff = wadd(rr[i], tend_apply(top, tp[i]));
+                    const int32_t diff = wadd(rr[i], tend_apply(top, tend_pre(av[i], av[i + 1])));
                     o1[i] = wadd(av[i], diff / 2);
                     o2[i] = wsub(o1[i], diff);
                     top = o2[i];
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
                 const int y = y0 + i;
                 if (y < ye) {
                     const int32_t t = y > ys ? top : av[i];
-                    const int32_t diff = wadd(rr[i], tend_apply(t, tp[i]));
+                    const int32_t diff = wadd(rr[i], tend_apply(t, tend_pre(av[i], av[i + 1])));
                     const int32_t first = wadd(av[i], diff / 2);
                     const int32_t second = wsub(first, diff);
                     if (keep) {
@@ -353,14 +351,11 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
                 // whole steps (full chunks and the warm-up chunk): straight-line code, no per-column guards on the chain
                 for (int i0 = 0; i0 < cols; i0 += U) {
                     int32_t va[U + 1], vr[U];
-                    TendPre tp[U];
 #pragma unroll
                     for (int j = 0; j <= U; j++) va[j] = pa[i0 + j];  // column `cols` is stale or padding: replaced below
 #pragma unroll
                     for (int j = 0; j < U; j++) vr[j] = pr[i0 + j];
                     if (i0 + U == cols) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
-#pragma unroll
-                    for (int j = 0; j < U; j++) tp[j] = tend_pre(va[j], va[j + 1]);
                     int32_t o1[U], o2[U];
                     TendFast tf[U];
 #pragma unroll
@@ -379,7 +374,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
                         left = left0;
 #pragma unroll
                         for (int j = 0; j < U; j++) {
-                            const int32_t diff = wadd(vr[j], tend_apply(left, tp[j]));
+                            const int32_t diff = wadd(vr[j], tend_apply(left, tend_pre(va[j], va[j + 1])));  // long form, built here: rare
                             o1[j] = wadd(va[j], diff / 2);
                             o2[j] = wsub(o1[j], diff);
                             left = o2[j];
