@@ -186,6 +186,12 @@ jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* ctx, const jxl_lfquant_desc* 
  * (PassGroup.java:174-200). */
 jxl_status jxl_vardct_put_group(jxl_ctx* ctx, int32_t pass, int32_t group,
                                 const int32_t* const q[3], const int32_t stride[3]);
+/* Host-side preparation a run needs and would otherwise do on first use: varblock binning by transform type
+ * (the device counterpart of walking HFMetadata.blockList, HFCoefficients.java:76-85), the chroma-from-luma
+ * cache-order masks (HFCoefficients.java:159-181), upload of the side tables, LF dequantisation jobs. Synchronous.
+ * Idempotent until the frame's inputs change; jxl_vardct_run calls it implicitly. bench.py times it as
+ * `host_prepare_ms`. */
+jxl_status jxl_vardct_prepare(jxl_ctx* ctx);
 /* Launch every enabled stage on the ctx stream; inputs are resident after put_group.
  * Asynchronous: returns after enqueue. Re-runnable (inputs are not consumed). */
 jxl_status jxl_vardct_run(jxl_ctx* ctx);

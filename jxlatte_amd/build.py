@@ -27,8 +27,10 @@ EXTRA = {"k_restore_fused": ["-fno-slp-vectorize"], "k_idct": ["-fno-slp-vectori
 
 def _deps():
     inc = os.path.join(HERE, "..", "include")
-    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    d += [os.path.join(inc, f) for f in os.listdir(inc)]
+    # sources only: the *.o outputs live in the same directory and must not count as inputs (they did: every call
+    # recompiled all but the newest object)
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
+    d += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     return d
 
 

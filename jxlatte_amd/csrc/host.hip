@@ -481,6 +481,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     for (int i = 0; i < 3; i++) {
         c->coeff[i].release(); c->lf[i].release(); c->llf[i].release(); c->lfq_tmp[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
     }
+    for (int i = 0; i < 3; i++) c->hfm_sub[i].release();
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++)
@@ -605,6 +606,8 @@ jxl_status jxl_vardct_set_weights(jxl_ctx* c, const float* w, size_t n_floats, c
     }
     memcpy(c->woffs, offs, sizeof c->woffs);
     c->have_weights = true;
+    c->tables_dirty = true;  // woffs and the weight buffers are captured by fill_dev_frame: cached batch argument blocks
+                             // (keyed on tables_gen) must not outlive them
     return JXL_OK;
 }
 
@@ -942,6 +945,13 @@ bool batchable(const jxl_ctx* c) {
 
 extern "C" {
 
+jxl_status jxl_vardct_prepare(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    return finalize_tables(c);
+}
+
 jxl_status jxl_vardct_run(jxl_ctx* c) { return run_frame(c, false); }
 
 // A batch of independent frames (one context each, all on one device): the IDCT stage of the whole batch runs as ONE
@@ -1072,7 +1082,9 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
         launch_restore_fused_batch(fa.data(), c0->batch_restore_args.as<FusedArgs>(), n, s0);
         (void)hipEventRecord(c0->batch_ev, s0);
         for (int i = 1; i < n; i++) (void)hipStreamWaitEvent(ctxs[i]->stream, c0->batch_ev, 0);
-        c0->last_launches += (int)c0->batch_launches.size() + 1;
+        // run_frame in collect mode has already counted the fused launch for every frame; the shared IDCT launches are
+        // attributed to the first context
+        c0->last_launches += (int)c0->batch_launches.size();
         return JXL_OK;
     }
     (void)hipEventRecord(c0->batch_ev, s0);

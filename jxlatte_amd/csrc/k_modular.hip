@@ -91,7 +91,10 @@ __device__ __forceinline__ TendFast tend_fast_pre(int32_t b, int32_t c) {
     t.b = b;
     t.ge = b >= c ? -1 : 0;
     t.le = b <= c ? -1 : 0;
-    t.unsafe = (uint32_t)wsub(b, c) + 0x20000000u >= 0x40000000u;
+    // the range test looks at the WRAPPED difference: a true |b - c| of 2^32 - 2^29 or more wraps into the safe window
+    // (b = INT_MAX, c = INT_MIN gives -1), so a subtraction that overflowed is unsafe by itself
+    const int32_t bmc = wsub(b, c);
+    t.unsafe = ((uint32_t)bmc + 0x20000000u >= 0x40000000u) || (((b ^ c) & (b ^ bmc)) < 0);
     return t;
 }
 
@@ -106,7 +109,7 @@ __device__ __forceinline__ int32_t tend_fast_apply(int32_t a, const TendFast& t,
     const int32_t lt = amb >> 31, gt = wsub(t.b, a) >> 31;
     const int32_t dec = t.ge & ~lt;         // b >= c && a >= b
     const int32_t inc = t.le & ~gt & ~dec;  // else b <= c && a <= b
-    unsafe = unsafe || t.unsafe || ((uint32_t)amb + 0x20000000u >= 0x40000000u);
+    unsafe = unsafe || t.unsafe || ((uint32_t)amb + 0x20000000u >= 0x40000000u) || (((a ^ t.b) & (a ^ amb)) < 0);
     return (xd & dec) | (xi & inc);
 }
 

@@ -119,7 +119,7 @@ _lib = None
 def build(force=False):
     """g++ build of the front-end (jxlatte_amd/frontend/Makefile)."""
     src = os.path.join(HERE, "frontend")
-    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src))
+    newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".cc", ".h")) or f == "Makefile")
     if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < newest:
         subprocess.check_call(["make", "-C", src, "-s"])
     return SO_PATH
@@ -128,8 +128,7 @@ def build(force=False):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            build()
+        build()  # mtime check against the sources: a stale front-end is never loaded silently
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)

@@ -63,10 +63,47 @@ void HFBlockContext::read(BitReader& br) {  // HFBlockContext.java:20-57
     num_clusters = read_cluster_map(br, cluster_map, 16);
 }
 
+// geometry of the part of `full` that sub-stream number `idx` of group size `dim` carries (Frame.java:276-290, 322-331).
+// Shifts come from squeeze bookkeeping on untrusted input: a shift that empties the group size would divide by zero in
+// ceil_div (Java: ArithmeticException) and a shift >= 32 is undefined behaviour, so both are reported.
+Channel sub_channel(const Channel& full, int dim, int idx) {
+    Channel c(full.h, full.w, full.vshift, full.hshift);
+    if (c.vshift < 0 || c.hshift < 0 || c.vshift > 30 || c.hshift > 30) throw BitstreamError("modular channel shift out of range");
+    const int gh = dim >> c.vshift, gw = dim >> c.hshift;
+    if (gh <= 0 || gw <= 0) throw BitstreamError("modular channel shift larger than the group size");
+    const int stride = ceil_div(c.w, gw);
+    if (stride <= 0) { c.h = c.w = 0; return c; }
+    c.oy = (idx / stride) * gh;
+    c.ox = (idx % stride) * gw;
+    c.h = std::min(c.h - c.oy, gh);
+    c.w = std::min(c.w - c.ox, gw);
+    if (c.h < 0 || c.w < 0) c.h = c.w = 0;
+    return c;
+}
+
+// copy a decoded sub-channel back into the frame-level channel. The sub-stream's own transforms (palette over channels of
+// unequal size, squeeze) can leave a channel with other dimensions or origin than requested; the reference then fails with
+// ArrayIndexOutOfBoundsException -- here it is an invalid bitstream, never a write outside dst.buf.
+void copy_back(Channel& dst, const Channel& src, const Channel& want) {
+    dst.allocate();
+    if (src.h != want.h || src.w != want.w || src.oy != want.oy || src.ox != want.ox)
+        throw BitstreamError("modular sub-stream returned a channel of the wrong size");
+    if (src.h == 0 || src.w == 0) return;
+    if (src.oy < 0 || src.ox < 0 || (int64_t)src.oy + src.h > dst.h || (int64_t)src.ox + src.w > dst.w)
+        throw BitstreamError("modular sub-stream channel leaves the frame channel");
+    if (src.buf.size() < (size_t)src.h * src.w) throw BitstreamError("modular sub-stream channel was not decoded");
+    for (int y = 0; y < src.h; y++) memcpy(dst.row(y + src.oy) + src.ox, src.row(y), sizeof(int32_t) * (size_t)src.w);
+}
+
 void Frame::read_header(BitReader& br, const ImageHeader& image) {  // Frame.readFrameHeader + readTOC
     ih = &image;
     br.align_to_byte();
     fh.read(br, image);
+    // untrusted geometry: the crop size is a 30-bit field per axis. Bound the frame exactly as the image is bounded (api.cc) so
+    // that every product below fits an int and the TOC cannot ask for gigabytes (the Java reference dies with
+    // OutOfMemoryError / NegativeArraySizeException here; this port reports it)
+    if (fh.width <= 0 || fh.height <= 0) throw BitstreamError("empty frame");
+    if ((int64_t)fh.width * fh.height > (1ll << 28)) throw UnsupportedError("frame larger than 2^28 pixels");
     group_cols = ceil_div(fh.width, fh.group_dim);
     lf_group_cols = ceil_div(fh.width, fh.group_dim << 3);
     num_groups = group_cols * ceil_div(fh.height, fh.group_dim);
@@ -81,8 +118,13 @@ void Frame::read_header(BitReader& br, const ImageHeader& image) {  // Frame.rea
         padded_h = fh.encoding == kVarDCT ? (h * fy) << 3 : h * fy;
         padded_w = fh.encoding == kVarDCT ? (w * fx) << 3 : w * fx;
     }
-    const uint32_t entries = (num_groups == 1 && fh.passes.num_passes == 1)
-                                 ? 1u : (uint32_t)(1 + num_lf_groups + 1 + num_groups * fh.passes.num_passes);
+    const int64_t entries64 = (num_groups == 1 && fh.passes.num_passes == 1)
+                                  ? 1 : 1 + (int64_t)num_lf_groups + 1 + (int64_t)num_groups * fh.passes.num_passes;
+    if (entries64 > (1ll << 22)) throw UnsupportedError("TOC with more than 2^22 entries");
+    // every entry costs at least 10 bits of TOC: refuse counts the remaining bytes cannot hold before allocating for them
+    if (entries64 * 10 > (int64_t)(br.size_bytes() - std::min(br.size_bytes(), br.byte_pos())) * 8 + 64)
+        throw BitstreamError("TOC larger than the codestream");
+    const uint32_t entries = (uint32_t)entries64;
     toc.read(br, entries);
     offsets_.assign(entries + 1, 0);
     for (uint32_t i = 0; i < entries; i++) offsets_[i + 1] = offsets_[i] + toc.lengths[i];
@@ -267,28 +309,14 @@ void Frame::read_lf_group(BitReader& br, int idx, std::vector<int>& replaced_idx
     // modular channels of the frame-level stream carried by this LF group (Frame.decodeLFGroups :262-300)
     {
         std::vector<Channel> sub;
-        for (int ci : replaced_idx) {
-            const Channel& full = global_modular.channels[ci];
-            Channel c(full.h, full.w, full.vshift, full.hshift);
-            const int gh = lfg_dim >> c.vshift, gw = lfg_dim >> c.hshift;
-            const int stride = ceil_div(c.w, gw);
-            c.oy = (idx / stride) * gh;
-            c.ox = (idx % stride) * gw;
-            c.h = std::min(c.h - c.oy, gh);
-            c.w = std::min(c.w - c.ox, gw);
-            if (c.h < 0 || c.w < 0) c.h = c.w = 0;
-            sub.push_back(c);
-        }
+        for (int ci : replaced_idx) sub.push_back(sub_channel(global_modular.channels[ci], lfg_dim, idx));
+        const std::vector<Channel> want = sub;
         ModularStream ms;
         ms.init(br, std::move(sub), 1 + num_lf_groups + idx, has_global_tree ? &global_tree : nullptr, ih->depth.bits);
         ms.decode_channels(br, false, fh.group_dim);
-        for (size_t j = 0; j < replaced_idx.size() && j < ms.channels.size(); j++) {
-            Channel& dst = global_modular.channels[replaced_idx[j]];
-            const Channel& src = ms.channels[j];
-            dst.allocate();
-            for (int y = 0; y < src.h; y++)
-                memcpy(dst.row(y + src.oy) + src.ox, src.row(y), sizeof(int32_t) * (size_t)src.w);
-        }
+        if (ms.channels.size() < replaced_idx.size() && !ms.empty) throw BitstreamError("modular sub-stream lost channels");
+        for (size_t j = 0; j < replaced_idx.size() && j < ms.channels.size(); j++)
+            copy_back(global_modular.channels[replaced_idx[j]], ms.channels[j], want[j]);
     }
     if (fh.encoding != kVarDCT) return;
     // HFMetadata
@@ -599,28 +627,15 @@ void Frame::read_hf_coefficients(BitReader& br, int pass, int group) {
 void Frame::read_pass_group(BitReader& br, int pass, int group, const std::vector<int>& replaced_idx) {  // PassGroup.java:50-63
     if (fh.encoding == kVarDCT) read_hf_coefficients(br, pass, group);
     std::vector<Channel> sub;
-    for (int ci : replaced_idx) {  // Frame.decodePassGroups :320-331
-        const Channel& full = global_modular.channels[ci];
-        Channel c(full.h, full.w, full.vshift, full.hshift);
-        const int gh = fh.group_dim >> c.vshift, gw = fh.group_dim >> c.hshift;
-        const int stride = ceil_div(c.w, gw);
-        c.oy = (group / stride) * gh;
-        c.ox = (group % stride) * gw;
-        c.h = std::min(c.h - c.oy, gh);
-        c.w = std::min(c.w - c.ox, gw);
-        if (c.h < 0 || c.w < 0) c.h = c.w = 0;
-        sub.push_back(c);
-    }
+    for (int ci : replaced_idx) sub.push_back(sub_channel(global_modular.channels[ci], fh.group_dim, group));  // Frame.decodePassGroups :320-331
+    const std::vector<Channel> want = sub;
     ModularStream ms;
     ms.init(br, std::move(sub), 18 + 3 * num_lf_groups + num_groups * pass + group, has_global_tree ? &global_tree : nullptr,
             ih->depth.bits);
     ms.decode_channels(br, false, fh.group_dim);
-    for (size_t j = 0; j < replaced_idx.size() && j < ms.channels.size(); j++) {
-        Channel& dst = global_modular.channels[replaced_idx[j]];
-        const Channel& src = ms.channels[j];
-        dst.allocate();
-        for (int y = 0; y < src.h; y++) memcpy(dst.row(y + src.oy) + src.ox, src.row(y), sizeof(int32_t) * (size_t)src.w);
-    }
+    if (ms.channels.size() < replaced_idx.size() && !ms.empty) throw BitstreamError("modular sub-stream lost channels");
+    for (size_t j = 0; j < replaced_idx.size() && j < ms.channels.size(); j++)
+        copy_back(global_modular.channels[replaced_idx[j]], ms.channels[j], want[j]);
 }
 
 void Frame::decode(BitReader& br, const TransformHooks* hooks) {  // Frame.decodeFrame (:376-461), front part

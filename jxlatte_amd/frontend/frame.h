@@ -64,6 +64,11 @@ struct HFPass {
     std::shared_ptr<EntropyCode> code;
 };
 
+// the part of a frame-level modular channel that sub-stream `idx` of group size `dim` carries, and the checked copy of the
+// decoded part back into it (frame.cc; both validate untrusted geometry and throw BitstreamError)
+Channel sub_channel(const Channel& full, int dim, int idx);
+void copy_back(Channel& dst, const Channel& src, const Channel& want);
+
 struct Frame {
     const ImageHeader* ih = nullptr;
     FrameHeader fh;

@@ -98,7 +98,14 @@ void ModularStream::init(BitReader& br, std::vector<Channel> chans, int stream_i
         if (t.tr == Transform::kPalette) {  // :92-102
             if (t.begin_c < nb_meta) nb_meta += 2 - t.num_c;
             else nb_meta++;
-            if (t.begin_c + t.num_c > (int)channels.size() || t.num_c < 1) throw BitstreamError("Palette channel range");
+            if (t.begin_c < 0 || t.begin_c + t.num_c > (int)channels.size() || t.num_c < 1) throw BitstreamError("Palette channel range");
+            // the inverse recreates the removed channels as copies of the index channel: they must all have had its shape
+            // (libjxl makes the same check; the Java reference runs into ArrayIndexOutOfBounds later)
+            for (int j = t.begin_c + 1; j < t.begin_c + t.num_c; j++) {
+                const Channel &a = channels[t.begin_c], &b = channels[j];
+                if (a.w != b.w || a.h != b.h || a.hshift != b.hshift || a.vshift != b.vshift)
+                    throw BitstreamError("Palette over channels of unequal size");
+            }
             const int start = t.begin_c + 1;
             channels.erase(channels.begin() + start, channels.begin() + t.begin_c + t.num_c);
             if (t.nb_deltas > 0 && t.d_pred == 6) channels[t.begin_c].force_wp = true;

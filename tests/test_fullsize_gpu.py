@@ -35,6 +35,48 @@ def test_4k_rerun_is_idempotent_and_group_order_free(ctx):
     assert_bits_equal(fr2.decodeFrame(), a, "reverse order")
 
 
+def test_c5_batch_of_4k_frames(orc):
+    """config C5's per-GPU share: 8 independent 4K frames (seeds 1000..1007, the frames rank 0 of 8 holds for
+    frames-per-gpu 8 are 1000, 1008, ...; the generator is the same) through per-frame runs on 8 contexts / streams and
+    through jxl_vardct_run_batch: identical planes both ways, two of them checked against the oracle"""
+    from jxlatte_amd import _lib
+    seeds = list(range(1000, 1008))
+    ctxs = [_lib.Context(0) for _ in seeds]
+    try:
+        synths = {}
+        frames = []
+        for c, sd in zip(ctxs, seeds):
+            fr = synth.make_vardct_frame(3840, 2160, seed=sd, mix="default")
+            if sd in (1000, 1005):
+                synths[sd] = fr
+            frames.append(host.Frame.from_synth(c, fr))
+        for fr in frames:          # what bench.py's step does
+            fr.run()
+        single = [fr.readOutput() for fr in frames]
+        host.Frame.runBatch(frames)
+        for i, fr in enumerate(frames):
+            assert_bits_equal(fr.readOutput(), single[i], "frame %d: batch vs single run" % seeds[i])
+        for sd, f in synths.items():
+            assert_bits_equal(single[seeds.index(sd)], orc.vardct_frame(f, threads=os.cpu_count()), "frame %d vs oracle" % sd)
+        assert not np.array_equal(single[0], single[1])  # distinct frames really are distinct
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_c4_8k_pq_u16_vs_oracle(ctx, orc):
+    """config C4 at its full size: 7680x4320, BT.2100-adapted opsin matrix, XYB -> linear -> PQ -> u16, against the oracle
+    (double-precision pow, TransferFunction.java:83-87): within one code value everywhere, identical almost everywhere"""
+    frame = synth.make_vardct_frame(7680, 4320, seed=4321, mix="default", transfer=abi.TRANSFER_PQ, out_format=abi.OUT_U16,
+                                    opsin_matrix=synth.bt2100_opsin_matrix(), intensity_target=10000.0)
+    got = host.Frame.from_synth(ctx, frame).decodeFrame()
+    exp = orc.vardct_frame(frame, threads=os.cpu_count())
+    assert got.shape == exp.shape == (3, 4320, 7680)
+    d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
+    assert d.max() <= 1, "PQ u16 differs by %d code values" % d.max()
+    assert (d != 0).mean() < 1e-3, "too many off-by-one code values: %g" % (d != 0).mean()
+
+
 def test_large_block_mix_frame(ctx, orc):
     """128/256-edge varblocks across several LF groups (2048-px boundary crossed)"""
     frame = synth.make_vardct_frame(2304, 512, seed=9, mix="large")

@@ -35,6 +35,28 @@ def test_squeeze_wraparound_and_tendency_branches(ctx, orc):
         assert_bits_equal(host.ModularChannel.inverseHorizontalSqueeze(ctx, a, r), orc.inv_hsqueeze(a, r), "ramp")
 
 
+def test_squeeze_overflowing_differences(ctx, orc):
+    """(left, avg, next) triples whose true differences exceed the int32 range -- (INT_MAX, INT_MIN, INT_MIN), alternating
+    extremes, extremes next to small values: the wrapped difference lands inside the fast path's "safe" window, so the
+    overflow itself has to send the lane to the exact form (k_modular.hip tend_fast_*)"""
+    lo, hi = -2 ** 31, 2 ** 31 - 1
+    rng = np.random.default_rng(31)
+    pool = np.array([hi, lo, lo, hi, hi, lo + 1, hi - 1, 0, -1, 1, lo, lo, hi, hi, 2 ** 30, -2 ** 30, hi, lo, 5, lo, hi, -7], np.int64)
+    rows = [pool, pool[::-1], np.resize(np.array([hi, lo]), pool.size), np.resize(np.array([lo, lo, hi]), pool.size)]
+    rows += [rng.choice(pool, size=pool.size) for _ in range(60)]
+    avg = np.array(rows, np.int64).astype(np.int32)
+    for res in (np.zeros_like(avg), rng.choice(np.array([hi, lo, 0, 1, -1, 12345], np.int64), size=avg.shape).astype(np.int32)):
+        assert_bits_equal(host.ModularChannel.inverseHorizontalSqueeze(ctx, avg, res), orc.inv_hsqueeze(avg, res), "overflow h")
+        at, rt = avg.T.copy(), res.T.copy()
+        assert_bits_equal(host.ModularChannel.inverseVerticalSqueeze(ctx, at, rt), orc.inv_vsqueeze(at, rt), "overflow v")
+    # long rows: the segmented walk (warm-up from a guessed state, verify, redo) over the same extremes
+    avg = rng.choice(pool, size=(70, 700)).astype(np.int32)
+    res = rng.choice(np.array([hi, lo, 0, 3, -3], np.int64), size=(70, 700)).astype(np.int32)
+    assert_bits_equal(host.ModularChannel.inverseHorizontalSqueeze(ctx, avg, res), orc.inv_hsqueeze(avg, res), "overflow h long")
+    assert_bits_equal(host.ModularChannel.inverseVerticalSqueeze(ctx, avg.T.copy(), res.T.copy()),
+                      orc.inv_vsqueeze(avg.T.copy(), res.T.copy()), "overflow v long")
+
+
 def test_squeeze_shape_errors(ctx):
     with pytest.raises((ValueError, _lib.IllegalArgumentException)):
         host.ModularChannel.inverseHorizontalSqueeze(ctx, np.zeros((4, 5), np.int32), np.zeros((4, 3), np.int32))

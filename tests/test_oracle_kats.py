@@ -405,6 +405,30 @@ def test_tendency_min_max_form(orc):
         c = b + rng.integers(-scale // 4 - 1, scale // 4 + 1, a.size)
         safe = (np.abs(a - b) < 2**29) & (np.abs(b - c) < 2**29)
         assert np.array_equal(ref(a, b, c)[safe], fast(a, b, c)[safe])
+    # the device's guard (k_modular.hip tend_fast_pre / tend_fast_apply): branch masks from the SIGN of the wrapped
+    # differences, `unsafe` = wrapped difference outside +-2^29 OR the subtraction overflowed. Over triples built from the
+    # int32 extremes every lane is either flagged unsafe (and redone with the long form) or already equal to the reference.
+    def dev_fast_and_guard(a, b, c):
+        amb, bmc = wrap(a - b), wrap(b - c)
+        lt, gt = amb < 0, wrap(b - a) < 0
+        dec = (b >= c) & ~lt
+        inc = (b <= c) & ~gt & ~dec
+        d, e = wrap(2 * amb), wrap(2 * bmc)
+        x = tdiv(wrap(4 * a - 3 * c - b + 6), 12)
+        y = tdiv(wrap(4 * a - 3 * c - b - 6), 12)
+        val = np.where(dec, np.minimum(np.minimum(x, wrap(d + 1)), e), np.where(inc, np.maximum(np.maximum(y, wrap(d - 1)), e), 0))
+
+        def ovf(p, q, diff):  # ((p ^ q) & (p ^ diff)) < 0 on int32
+            return ((p < 0) != (q < 0)) & ((p < 0) != (diff < 0))
+        unsafe = (np.abs(amb) >= 2**29) | (np.abs(bmc) >= 2**29) | ovf(a, b, amb) | ovf(b, c, bmc)
+        return val, unsafe
+    lo, hi = -2**31, 2**31 - 1
+    ext = np.array([hi, lo, hi - 1, lo + 1, hi - 2**29, lo + 2**29, 2**30, -2**30, 2**29, -2**29, 2**29 - 1, 0, 1, -1, 7, -9], np.int64)
+    A, B, C = np.meshgrid(ext, ext, ext, indexing="ij")
+    val, unsafe = dev_fast_and_guard(A, B, C)
+    assert np.array_equal(val[~unsafe], ref(A, B, C)[~unsafe])
+    assert unsafe[0, 1, 1]                      # (INT_MAX, INT_MIN, INT_MIN): a - b wraps to -1
+    assert (ref(A, B, C)[unsafe] != val[unsafe]).any()  # the guard is not vacuous: the short form does differ there
     # the numpy restatement itself agrees with the oracle: row [avg, next] with residual r gives out[1] = avg + t/2... use
     # the two-pair row (avg0, avg1), residuals (0, r): second pair has left = out[1] of the first
     a = rng.integers(-1000, 1000, (2000, 2)).astype(np.int32)

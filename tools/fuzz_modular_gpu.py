@@ -7,27 +7,42 @@ import numpy as np
 from jxlatte_amd import _lib, host, synth
 from oracle import pyoracle as orc
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
-ctx = _lib.Context(0)
-bad = 0
-sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 130, 160, 255, 257, 300, 511, 513, 700]
-for case in range(n_cases):
-    w, h = int(rng.choice(sizes)), int(rng.choice(sizes))
-    ch = int(rng.integers(1, 5))
-    scale = float(rng.choice([0.0, 1.0, 4.0, 300.0, 2e6, 5e8]))
-    os.environ["JXL_HSQUEEZE_WALK_MAX"] = "0" if rng.integers(0, 2) else str(1 << 40)
-    mod = synth.make_modular_frame(w, h, channels=ch, seed=int(rng.integers(1, 1 << 30)), res_scale=max(scale, 1e-9))
-    if scale == 0.0:
-        for a in mod["chans"][ch:]:
-            a[:] = 0
-    rct = int(rng.integers(-1, 42)) if ch >= 3 else -1
-    ms = host.ModularStream(ctx, mod["chans"], mod["sp"], rctType=rct, rctBegin=0)
-    out = ms.applyTransforms()
-    exp = orc.modular_apply(mod["chans"], mod["sp"], rct_type=rct, rct_begin=0)
-    ok = len(out) == len(exp) and all(np.array_equal(a, b) for a, b in zip(out, exp))
-    if not ok:
-        bad += 1
-        print("MISMATCH case %d: %dx%d ch=%d scale=%g rct=%d walk_max=%s" % (case, w, h, ch, scale, rct, os.environ["JXL_HSQUEEZE_WALK_MAX"]))
-print("modular fuzz: %d cases, %d mismatches" % (n_cases, bad))
-sys.exit(1 if bad else 0)
+
+def run(n_cases=60, seed=11, device=0, verbose=True):
+    """returns the number of mismatching images"""
+    rng = np.random.default_rng(seed)
+    ctx = _lib.Context(device)
+    bad = 0
+    sizes = [1, 2, 7, 8, 9, 63, 64, 65, 127, 128, 129, 130, 160, 255, 257, 300, 511, 513, 700]
+    saved = os.environ.get("JXL_HSQUEEZE_WALK_MAX")
+    try:
+        for case in range(n_cases):
+            w, h = int(rng.choice(sizes)), int(rng.choice(sizes))
+            ch = int(rng.integers(1, 5))
+            scale = float(rng.choice([0.0, 1.0, 4.0, 300.0, 2e6, 5e8]))
+            os.environ["JXL_HSQUEEZE_WALK_MAX"] = "0" if rng.integers(0, 2) else str(1 << 40)
+            mod = synth.make_modular_frame(w, h, channels=ch, seed=int(rng.integers(1, 1 << 30)), res_scale=max(scale, 1e-9))
+            if scale == 0.0:
+                for a in mod["chans"][ch:]:
+                    a[:] = 0
+            rct = int(rng.integers(-1, 42)) if ch >= 3 else -1
+            ms = host.ModularStream(ctx, mod["chans"], mod["sp"], rctType=rct, rctBegin=0)
+            out = ms.applyTransforms()
+            exp = orc.modular_apply(mod["chans"], mod["sp"], rct_type=rct, rct_begin=0)
+            ok = len(out) == len(exp) and all(np.array_equal(a, b) for a, b in zip(out, exp))
+            if not ok:
+                bad += 1
+                print("MISMATCH case %d: %dx%d ch=%d scale=%g rct=%d walk_max=%s" % (case, w, h, ch, scale, rct, os.environ["JXL_HSQUEEZE_WALK_MAX"]))
+    finally:
+        ctx.close()
+        if saved is None:
+            os.environ.pop("JXL_HSQUEEZE_WALK_MAX", None)
+        else:
+            os.environ["JXL_HSQUEEZE_WALK_MAX"] = saved
+    if verbose:
+        print("modular fuzz: %d cases, %d mismatches" % (n_cases, bad))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 11) else 0)
