@@ -429,6 +429,7 @@ def main():
 def gather_legs(args, torch, dist, shard, lib, ctxs, frames, step, sync_all, n_frames, rank, world, H, W):
     """time (i) the gather of one step's output alone and (ii) K steps of compute with the gather of step k overlapping the
     compute of step k+1; both as max over ranks. The send tensor is [k, 3, H, W] of the output element type."""
+    step()  # the output element size is known once a frame has run
     es = lib.jxl_vardct_out_elem_size(ctxs[0].h)
     k = len(ctxs)
     # f32 planes as float32 [k, 3, H, W]; narrower outputs as raw bytes (RCCL has no uint16): [k, 3, H, W * es] uint8

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libjxlatte_amd.so")
-SOURCES = ["k_idct.hip", "k_restore.hip", "k_restore_fused.hip", "k_modular.hip", "k_lf.hip", "k_post.hip", "host.hip"]
+SOURCES = ["k_idct.hip", "k_idct_wg3.hip", "k_restore.hip", "k_restore_fused.hip", "k_modular.hip", "k_lf.hip", "k_post.hip", "host.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # k_restore_fused: hipcc's SLP vectoriser packs the EPF distance terms into v_pk_* pairs but pays for it with ~50 register
 # moves and 35 v_and (abs) per channel iteration; scalar code with free |x| source modifiers is 12 % faster (measured).
 # k_idct: the IDCT cores use explicit packed vectors; auto-SLP on the 8x8 special transforms costs 19 % (same symptom).
-EXTRA = {"k_restore_fused": ["-fno-slp-vectorize"], "k_idct": ["-fno-slp-vectorize"]}
+EXTRA = {"k_restore_fused": ["-fno-slp-vectorize"], "k_idct": ["-fno-slp-vectorize"], "k_idct_wg3": ["-fno-slp-vectorize"]}
 
 
 def _deps():
@@ -34,18 +34,23 @@ def _deps():
     return d
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, tag=None, defines=()):
+    """tag / defines: an experiment build next to the product one -- libjxlatte_amd_<tag>.so with -D<define>... on every file
+    (objects under csrc/obj_<tag>/); select it at run time with JXL_AMD_LIB=<path>"""
     newest = max(os.path.getmtime(p) for p in _deps())
+    so = SO if not tag else os.path.join(HERE, "libjxlatte_amd_%s.so" % tag)
+    objdir = CSRC if not tag else os.path.join(CSRC, "obj_" + tag)
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     jobs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
             stem = src.replace(".hip", "")
             extra = os.environ.get("JXL_EXTRA_" + stem, None)
             extra = extra.split() if extra is not None else EXTRA.get(stem, [])
-            jobs.append([HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
+            jobs.append([HIPCC] + FLAGS + extra + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj])
     if jobs:
         def run(cmd):
             if verbose:
@@ -58,13 +63,14 @@ def build(force=False, verbose=False):
             for err in ex.map(run, jobs):
                 if verbose and err.strip():
                     print(err)
-    if jobs or not os.path.exists(SO):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    if jobs or not os.path.exists(so):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
-    return SO
+    return so
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), None)
+    print(build(force="--force" in sys.argv, verbose=True, tag=tag, defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

@@ -119,7 +119,7 @@ struct jxl_ctx {
     static constexpr int kAux = 12;
     int n_aux = 1;  // side streams in use (JXL_AUX_STREAMS overrides). 1 is the batch-throughput optimum; 3 gives the lowest single-frame latency
     hipStream_t aux[kAux] = {};
-    hipEvent_t fork_ev = nullptr, join_ev[kAux] = {};
+    hipEvent_t fork_ev = nullptr, llf_ev = nullptr, join_ev[kAux] = {};
 
     // ---- Modular state
     std::vector<DevBuf> mod_bufs;
@@ -241,12 +241,17 @@ jxl_status finalize_tables(jxl_ctx* c) {
                 c->h_blocks.insert(c->h_blocks.end(), lists[t].begin(), lists[t].end());
             }
         const uint32_t ch0 = channel < 0 ? 0 : (uint32_t)channel, ch1 = channel < 0 ? 3 : (uint32_t)channel + 1;
-        jxl_ctx::TypeLaunch cl[2] = {{1, channel, {}}, {0, channel, {}}};  // launch order: heaviest class first
+        // classes 2 / 3 = the persistent three-channel kernel (k_idct_wg3.hip; 3: the 64-point family) for every METHOD_DCT type
+        // above 8x8 of a frame without chroma subsampling; classes 1 / 0 = the per-channel kernels of k_idct.hip (8x8 always; everything for
+        // subsampled frames, whose channels have their own geometry)
+        static const bool use_wg3 = !(getenv("JXL_IDCT_WG3") && atoi(getenv("JXL_IDCT_WG3")) == 0);
+        jxl_ctx::TypeLaunch cl[4] = {{3, channel, {}}, {2, channel, {}}, {1, channel, {}}, {0, channel, {}}};  // launch order: heaviest class first
         for (int t : kOrder) {
             if (lists[t].empty()) continue;
             const IdctSegment sg{t, (int)first_of[t], (int)lists[t].size()};
+            const int cls = (use_wg3 && channel < 0 && wg3_handles(t)) ? (wg3_big(t) ? 3 : 2) : idct_class_of(t);
             for (auto& l : cl)
-                if (l.cls == idct_class_of(t)) l.segs.push_back(sg);
+                if (l.cls == cls) l.segs.push_back(sg);
         }
         for (auto& l : cl)
             if (!l.segs.empty()) c->type_launches.push_back(std::move(l));
@@ -462,6 +467,7 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->llf_ev, hipEventDisableTiming);
     if (const char* e = getenv("JXL_AUX_STREAMS")) c->n_aux = std::max(0, std::min((int)jxl_ctx::kAux, atoi(e)));
     for (int i = 0; i < c->n_aux; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
@@ -487,6 +493,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
         for (int j = 0; j < 3; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->llf_ev) (void)hipEventDestroy(c->llf_ev);
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     c->batch_args.release();
     c->batch_restore_args.release();
@@ -586,24 +593,38 @@ jxl_status jxl_vardct_set_weights(jxl_ctx* c, const float* w, size_t n_floats, c
             if (o < 0 || (size_t)o + (size_t)mh * mw > n_floats) return fail(c, JXL_ERR_INVALID_ARGUMENT, "weight offset %d out of range", o);
         }
     }
-    if (!c->weights.ensure(sizeof(float) * n_floats) || !c->weights_t.ensure(sizeof(float) * n_floats))
-        return fail(c, JXL_ERR_OOM, "device allocation failed (weights)");
-    HIP_TRY(c, hipMemcpy(c->weights.p, w, sizeof(float) * n_floats, hipMemcpyHostToDevice));
-    {   // transposed copy of every matrix: flip() blocks index w3[x][y] (HFCoefficients.java:312-314)
-        std::vector<float> wt(w, w + n_floats);
-        for (int pi = 0; pi < JXL_NUM_WEIGHT_SETS; pi++) {
-            int mh = 0, mw = 0;
-            for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
-                if (JXL_TT[t].param_index == pi && !(JXL_TT[t].ph > JXL_TT[t].pw)) { mh = jxl_tt_mh(&JXL_TT[t]); mw = jxl_tt_mw(&JXL_TT[t]); break; }
-            for (int ch = 0; ch < 3; ch++) {
-                const float* src = w + offs[pi * 3 + ch];
-                float* dst = wt.data() + offs[pi * 3 + ch];
-                for (int y = 0; y < mh; y++)
-                    for (int x = 0; x < mw; x++) dst[(size_t)x * mh + y] = src[(size_t)y * mw + x];
-            }
+    // device layout: every matrix at a 16-byte aligned offset of the library's own (the kernels move weight rows as float4),
+    // plus a transposed copy of every matrix for flip() blocks, which index w3[x][y] (HFCoefficients.java:312-314)
+    int32_t doffs[51];
+    size_t total = 0;
+    int mhs[JXL_NUM_WEIGHT_SETS], mws[JXL_NUM_WEIGHT_SETS];
+    for (int pi = 0; pi < JXL_NUM_WEIGHT_SETS; pi++) {
+        int mh = 0, mw = 0;
+        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+            if (JXL_TT[t].param_index == pi && !(JXL_TT[t].ph > JXL_TT[t].pw)) { mh = jxl_tt_mh(&JXL_TT[t]); mw = jxl_tt_mw(&JXL_TT[t]); break; }
+        mhs[pi] = mh; mws[pi] = mw;
+        for (int ch = 0; ch < 3; ch++) {
+            doffs[pi * 3 + ch] = (int32_t)total;
+            total += ((size_t)mh * mw + 3) & ~(size_t)3;
         }
-        HIP_TRY(c, hipMemcpy(c->weights_t.p, wt.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice));
     }
+    std::vector<float> wd(total, 0.0f), wt(total, 0.0f);
+    for (int pi = 0; pi < JXL_NUM_WEIGHT_SETS; pi++)
+        for (int ch = 0; ch < 3; ch++) {
+            const float* src = w + offs[pi * 3 + ch];
+            float* dst = wd.data() + doffs[pi * 3 + ch];
+            float* dstt = wt.data() + doffs[pi * 3 + ch];
+            const int mh = mhs[pi], mw = mws[pi];
+            memcpy(dst, src, sizeof(float) * (size_t)mh * mw);
+            for (int y = 0; y < mh; y++)
+                for (int x = 0; x < mw; x++) dstt[(size_t)x * mh + y] = src[(size_t)y * mw + x];
+        }
+    if (!c->weights.ensure(sizeof(float) * total) || !c->weights_t.ensure(sizeof(float) * total))
+        return fail(c, JXL_ERR_OOM, "device allocation failed (weights)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // an earlier run may still be reading the old tables
+    HIP_TRY(c, hipMemcpy(c->weights.p, wd.data(), sizeof(float) * total, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->weights_t.p, wt.data(), sizeof(float) * total, hipMemcpyHostToDevice));
+    offs = doffs;
     memcpy(c->woffs, offs, sizeof c->woffs);
     c->have_weights = true;
     c->tables_dirty = true;  // woffs and the weight buffers are captured by fill_dev_frame: cached batch argument blocks
@@ -796,30 +817,101 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             }
             return fc;
         };
-        // fork: every type kernel writes a disjoint set of varblocks
+        // classes 2 / 3 (k_idct_wg3.hip): argument blocks of the two persistent launches and of the LLF launch in front
+        static const int wg3_grid = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 768;
+        static const int wg3_grid_big = getenv("JXL_WG3_GRID_BIG") ? atoi(getenv("JXL_WG3_GRID_BIG")) : 512;
+        Wg3Args wa[2], wl;
+        int wn[2] = {0, 0};
+        bool any_llf = false;
+        {
+            std::vector<IdctSegment> all;
+            for (const auto& tl : c->type_launches)
+                if (tl.cls >= 2) {
+                    wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
+                    all.insert(all.end(), tl.segs.begin(), tl.segs.end());
+                }
+            if (!all.empty()) {
+                build_wg3_args(f, blocks, all.data(), (int)all.size(), 2, A, wl);
+                for (int q = 0; q < wl.n_seg; q++) any_llf = any_llf || wl.seg[q].type != 0;
+            }
+        }
         const int n_k = (int)c->type_launches.size() + (int)c->special_launches.size();
         const bool fork = n_k > 1 && c->n_aux > 0;
-        int used = 0;
-        if (fork) {
-            (void)hipEventRecord(c->fork_ev, s);
-            used = std::min(n_k - 1, c->n_aux);
-            for (int i = 0; i < used; i++) (void)hipStreamWaitEvent(c->aux[i], c->fork_ev, 0);
-        }
-        int k = 0;
-        auto pick = [&]() { const int i = k++; return (!fork || i % (used + 1) == 0) ? s : c->aux[i % (used + 1) - 1]; };
-        for (const auto& tl : c->type_launches) {
-            launch_idct_multi(frame_of(tl.channel), blocks, tl.cls, tl.segs.data(), (int)tl.segs.size(), tl.channel < 0 ? 3 : 1, tl.channel < 0 ? 0 : tl.channel, A, pick());
-            launches++;
-        }
-        for (const auto& sl : c->special_launches) {
-            launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, pick());
-            launches++;
-        }
-        if (fork)
-            for (int i = 0; i < used; i++) {
-                (void)hipEventRecord(c->join_ev[i], c->aux[i]);
-                (void)hipStreamWaitEvent(s, c->join_ev[i], 0);
+        if (wn[0] > 0 || wn[1] > 0) {
+            // Frame without chroma subsampling. The long pole is the persistent launch of everything up to 32 points (with the
+            // 8x8 DCTs: ~80 % of the pixels): it goes on the main stream right behind the LLF launch it depends on. The special
+            // 8x8 transforms need no LLF and start at once on the side stream; the 64-point family follows them there, behind an
+            // event that says the LLF planes are written. (Measured on the 4K default mix: LLF as two launches in front of
+            // everything, the special kernel queued behind the 64-point launch: 112 us; this order: see profiles/.)
+            hipStream_t side = fork ? c->aux[0] : s;
+            if (fork) {
+                (void)hipEventRecord(c->fork_ev, s);
+                (void)hipStreamWaitEvent(side, c->fork_ev, 0);
             }
+            for (const auto& sl : c->special_launches) {
+                launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, side);
+                launches++;
+            }
+            if (any_llf) {
+                float* L[3] = {c->llf[0].as<float>(), c->llf[1].as<float>(), c->llf[2].as<float>()};
+                launch_llf_wg3(wl, L, s);
+                launches++;
+                if (fork && wn[1] > 0) {
+                    (void)hipEventRecord(c->llf_ev, s);  // "LLF planes written"
+                    (void)hipStreamWaitEvent(side, c->llf_ev, 0);
+                }
+            }
+            static const int plan = getenv("JXL_WG3_PLAN") ? atoi(getenv("JXL_WG3_PLAN")) : 0;
+            hipStream_t s_small = plan == 1 ? side : s, s_big = plan == 1 ? s : side;
+            if (plan == 1 && fork && any_llf && wn[0] > 0 && wn[1] <= 0) {
+                (void)hipEventRecord(c->llf_ev, s);
+                (void)hipStreamWaitEvent(side, c->llf_ev, 0);
+            }
+            if (plan == 1 && wn[1] > 0) {
+                launch_idct_wg3(wa[1], true, wg3_grid_big, s_big);
+                launches++;
+            }
+            if (wn[0] > 0) {
+                launch_idct_wg3(wa[0], false, wg3_grid, s_small);
+                launches++;
+            }
+            if (plan != 1 && wn[1] > 0) {
+                launch_idct_wg3(wa[1], true, wg3_grid_big, s_big);
+                launches++;
+            }
+            for (const auto& tl : c->type_launches)  // nothing today: every class 0 / 1 type of such a frame is handled above
+                if (tl.cls < 2) {
+                    launch_idct_multi(frame_of(tl.channel), blocks, tl.cls, tl.segs.data(), (int)tl.segs.size(), 3, 0, A, s);
+                    launches++;
+                }
+            if (fork) {
+                (void)hipEventRecord(c->join_ev[0], side);
+                (void)hipStreamWaitEvent(s, c->join_ev[0], 0);
+            }
+        } else {
+            // fork: every type kernel writes a disjoint set of varblocks
+            int used = 0;
+            if (fork) {
+                (void)hipEventRecord(c->fork_ev, s);
+                used = std::min(n_k - 1, c->n_aux);
+                for (int i = 0; i < used; i++) (void)hipStreamWaitEvent(c->aux[i], c->fork_ev, 0);
+            }
+            int k = 0;
+            auto pick = [&]() { const int i = k++; return (!fork || i % (used + 1) == 0) ? s : c->aux[i % (used + 1) - 1]; };
+            for (const auto& tl : c->type_launches) {
+                launch_idct_multi(frame_of(tl.channel), blocks, tl.cls, tl.segs.data(), (int)tl.segs.size(), tl.channel < 0 ? 3 : 1, tl.channel < 0 ? 0 : tl.channel, A, pick());
+                launches++;
+            }
+            for (const auto& sl : c->special_launches) {
+                launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, pick());
+                launches++;
+            }
+            if (fork)
+                for (int i = 0; i < used; i++) {
+                    (void)hipEventRecord(c->join_ev[i], c->aux[i]);
+                    (void)hipStreamWaitEvent(s, c->join_ev[i], 0);
+                }
+        }
         if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
     }
     // Frame.invertSubsampling (Frame.java:457, 681-723): horizontal doublings, then vertical ones, per channel
@@ -939,6 +1031,8 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
 
 // frames whose IDCT stage can share launches: plain 4:4:4 frames made of the merged-launch types
 bool batchable(const jxl_ctx* c) {
+    for (const auto& tl : c->type_launches)
+        if (tl.cls >= 2) return false;  // the persistent kernel has no batched form: such frames run one by one
     return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && (c->p.stages & JXL_STAGE_IDCT);
 }
 }  // namespace
@@ -1124,15 +1218,20 @@ jxl_status jxl_vardct_read_output(jxl_ctx* c, void* const out[3], int64_t out_st
     if (!out || out_stride < c->W) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output planes");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t es = (size_t)c->result_elem;
+    // dense destination rows (the usual case): one linear copy per buffer -- hipMemcpy2D into pageable memory goes row by row
+    // (measured: 31 ms for a 25 MB RGB8 4K frame against 3 ms linear)
+    const bool dense = out_stride == c->W;
     if (c->result_interleaved) {  // one buffer, rows of 3*W samples; out_stride counts pixels
         if (!out[0]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output buffer");
-        HIP_TRY(c, hipMemcpy2D(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
-                               hipMemcpyDeviceToHost));
+        if (dense) HIP_TRY(c, hipMemcpy(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost));
+        else HIP_TRY(c, hipMemcpy2D(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
+                                    hipMemcpyDeviceToHost));
         return JXL_OK;
     }
     for (int i = 0; i < 3; i++) {
         if (!out[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane %d", i);
-        HIP_TRY(c, hipMemcpy2D(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H, hipMemcpyDeviceToHost));
+        if (dense) HIP_TRY(c, hipMemcpy(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost));
+        else HIP_TRY(c, hipMemcpy2D(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H, hipMemcpyDeviceToHost));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "device error: %s", hipGetErrorString(e));

@@ -98,6 +98,24 @@ struct MultiArgs {
 // medium_blocks_per_wg(type) consecutive blocks (no item table to load before the block records)
 struct IdctSegment { int type, first_block, n_blocks; };
 
+// Argument block of the persistent three-channel IDCT launch (k_idct_wg3.hip): type-uniform segments in launch order
+struct Wg3Seg { int type, first_block, n_blocks, item_base; };  // item_base: index of the segment's first work item in the launch
+struct Wg3Args {
+    static constexpr int kMaxSeg = 12;
+    DevFrame f;
+    const DevBlock* blocks;
+    float *o0, *o1, *o2;
+    int n_seg, total_items;
+    int img_floats;  // floats of the largest three-channel LDS image among the segments' types (the tables follow it)
+    Wg3Seg seg[kMaxSeg];
+};
+bool wg3_handles(int type);
+bool wg3_big(int type);  // the 64-point family: its own launch (register / LDS class)
+int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],
+                   Wg3Args& a);
+void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s);
+void launch_idct_wg3(const Wg3Args& a, bool big, int grid_cap, hipStream_t s);
+
 // ---- launchers (defined in the kernel TUs) ---------------------------------------------------
 // One launch per register class (0: every type up to 32x32, 1: the 64-point family), 256-thread workgroups.
 // WorkItem.type = TransformType.type | channel << 8; an item covers up to medium_blocks_per_wg(type) blocks of that channel.

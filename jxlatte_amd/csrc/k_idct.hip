@@ -65,6 +65,23 @@ __device__ __forceinline__ DevBlock load_block(const DevBlock* blocks, int i) {
     return b;
 }
 
+// Diagnostic build only (-DJXL_STAMPS, tools/idct_stamps.py): lane 0 of every workgroup writes s_memtime at the phase
+// boundaries of its work item to a buffer of its own; no product build contains a stamp.
+#ifdef JXL_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;  // [workgroup][8]
+#define JXL_STAMP(i)                                                                                              \
+    do {                                                                                                          \
+        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define JXL_STAMP_VAL(i, v)                                                                       \
+    do {                                                                                          \
+        if (g_stamps && threadIdx.x == 0) g_stamps[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)(v); \
+    } while (0)
+#else
+#define JXL_STAMP(i)
+#define JXL_STAMP_VAL(i, v)
+#endif
+
 static constexpr float kAfv[16][16] = JXL_AFV_BASIS_INIT;
 __constant__ float kLlfScale[32] = JXL_LLF_SCALE_INIT;
 
@@ -722,6 +739,8 @@ __device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* 
     float* qtab = lds_wg + 4 * Cfg::BPW * IMG + wave * 64;
     const int bi_col = lane / W, x = lane % W;
     const int bi_row = lane / H, y = lane % H;
+    JXL_STAMP(0);
+    JXL_STAMP_VAL(7, TYPE);
     DevBlock b_col{}, b_row{};
     if (bi_col < nb) b_col = load_block(blocks, wfirst + bi_col);
     if (bi_row < nb) b_row = load_block(blocks, wfirst + bi_row);
@@ -796,7 +815,9 @@ __device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* 
             for (int k = 0; k < W; k += 4) *reinterpret_cast<float4*>(o + k) = make_float4(acc.get(k), acc.get(k + 1), acc.get(k + 2), acc.get(k + 3));
         }
         wave_lds_fence();  // the row pass has read the image before the next channel's column pass overwrites it
+        JXL_STAMP(1 + pass);
     }
+    JXL_STAMP(5);
 }
 
 // finalizeLLF (HFCoefficients.java:194-229) of every block larger than 8x8, written over the block's own cells
@@ -850,6 +871,8 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
     float* img1 = lds + NBLK * IMG;  // column-pass output
     float* qtab = lds + 2 * NBLK * IMG;
     const float qbn = f.quant_bias_numerator;
+    JXL_STAMP(0);
+    JXL_STAMP_VAL(7, TYPE);
     if (tid < 64) qtab[tid] = tid > 0 ? qbn / (float)tid : 0.0f;
     __syncthreads();
     // 1. dequant + CfL + LLF -> img0. Sample s = j*256 + tid of the NBLK blocks (x fastest: coalesced rows); all
@@ -892,6 +915,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
                 }
             }
         }
+        JXL_STAMP(1);
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             const int bi = j / BSTEP, n = (j % BSTEP) * RSTEP + r0;
@@ -916,6 +940,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         }
     }
     __syncthreads();
+    JXL_STAMP(2);
     // 2. column pass: lanes enumerate (chunk, block, column), x fastest
     {
         constexpr int KC = Cfg::KC_COL;
@@ -942,6 +967,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
         }
     }
     __syncthreads();
+    JXL_STAMP(3);
     // 3. row pass: lanes enumerate (chunk, block, row), y fastest; each lane stores KC consecutive outputs
     {
         constexpr int KC = Cfg::KC_ROW;
@@ -958,6 +984,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
                 acc.template step<true>(row[n], lut + (n - 1) * W);
                 if (n + 1 < W) acc.template step<false>(row[n + 1], lut + n * W);
             }
+            JXL_STAMP(4);
             // two runs of KC/2 consecutive outputs: the low one ascending, the mirrored one ending at W-1-kc*KC/2
             float* o = out + (int64_t)(b.cy * 8 + y) * FW + b.cx * 8;
             float* olo = o + kc * (KC / 2);
@@ -970,6 +997,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             }
         }
     }
+    JXL_STAMP(5);
 }
 
 // which types take the workgroup-level (LDS-staged, k-split) path instead of the wave-level streamed one
@@ -1065,6 +1093,13 @@ __global__ __launch_bounds__(256, CLASS == 0 ? 8 : 4) void k_idct_multi_batch(co
 }
 
 size_t medium_lds_bytes(int type);
+
+#ifdef JXL_STAMPS
+extern "C" int jxl_debug_set_stamps(void* dev_ptr) {
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof p);
+}
+#endif
 
 int idct_class_of(int type) { return (type == 18 || type == 19 || type == 20 || type == 4 || type == 6) ? 1 : 0; }
 

@@ -1,0 +1,726 @@
+// VarDCT stage 1, METHOD_DCT varblocks of 16..64 points per side (and the 8-point rectangles): dequantisation +
+// chroma-from-luma + LLF + inverse DCT of all THREE channels of a group of varblocks per workgroup, as a persistent,
+// software-pipelined kernel.
+//
+// Replaces (J/ = java/com/traneptora/jxlatte/):
+//   J/frame/vardct/HFCoefficients.java:140-319  bakeDequantizedCoeffs (dequant, CfL, finalizeLLF)
+//   J/frame/group/PassGroup.java:229-233        METHOD_DCT branch of invertVarDCT
+//   J/util/MathHelper.java:68-136               inverseDCT2D (columns, then rows), forwardDCT2D for the LLF corner
+//
+// Why this shape (measured with per-phase s_memtime stamps, round 2): in the per-channel kernels of k_idct.hip a 32x32 work
+// item spent 73 % of its life loading and dequantising (25 k of 34 k cycles) and 21 % in the two transform passes; chroma
+// items loaded and dequantised luma again; every sample fetched its weight and its CfL factor on its own. Here
+//   * one work item = NB varblocks x 3 channels (2048 sample positions per channel, 4096 for the 64-point family): luma is
+//     dequantised once and feeds chroma-from-luma of X and B in registers; coefficient rows, weights and block records
+//     move as 16-byte loads (4 consecutive x per lane);
+//   * the workgroup is persistent: it walks the frame's items (all types of its register class, costliest type first)
+//     with stride gridDim, and everything item i+1 needs from memory -- block records one item earlier still, then
+//     coefficients, weights, CfL factors, LLF coefficients -- is requested while item i is in its transform passes: the
+//     HBM latency that dominated every item overlaps with arithmetic of the same wave. The prefetch is type-generic
+//     (run-time geometry), so the pipeline runs across type boundaries; only the arithmetic is specialised per type;
+//   * workgroup barriers order LDS traffic only (lds_barrier): __syncthreads() would wait for the prefetch;
+//   * both passes work on ONE LDS image per channel in place (read column -> barrier -> write column): 3 channels of 2048
+//     positions fit 27 KB;
+//   * a lane produces 8 (16 for the 64-point family) outputs of its column / row with the mirrored-product trick of
+//     k_idct.hip (lut[n-1][N-1-k] == (-1)^n lut[n-1][k] bit for bit), the three channels interleaved so that one scalar
+//     load of the LUT slice feeds 18 (36) packed operations, four steps per loop trip with the next trip's LUT slices and
+//     LDS samples requested ahead;
+//   * finalizeLLF runs as a small kernel of its own before (k_llf_wg3: one lane per LLF coefficient into the llf planes).
+// Bit-exactness: every sum keeps the reference's order, multiplies and adds are separate IEEE f32 operations.
+#include "jxl_internal.h"
+#include "../../include/jxl_tables.h"
+
+namespace jxl {
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) float* cfloatp;
+typedef const __attribute__((address_space(4))) v2f* cv2fp;
+typedef const __attribute__((address_space(4))) v4i* cv4ip;
+
+__constant__ float kLlfScale3[32] = JXL_LLF_SCALE_INIT;
+
+// Diagnostic build only (-DJXL_STAMPS): lane 0 of every workgroup records s_memtime at the phase boundaries of its first
+// two items (rows 2*wg and 2*wg+1 of the stamp buffer)
+#ifdef JXL_STAMPS
+__device__ unsigned long long* g_stamps3 = nullptr;
+#define STAMP3(i)                                                                                                        \
+    do {                                                                                                                 \
+        if (g_stamps3 && threadIdx.x == 0 && it_no < 2) g_stamps3[((size_t)blockIdx.x * 2 + it_no) * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP3(i)
+#endif
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() carries a workgroup-scope release fence over ALL address
+// spaces, which the compiler lowers to s_waitcnt vmcnt(0): every global load in flight -- the prefetch of the next item --
+// would be waited for at the next barrier and the software pipeline would collapse (measured: the first version of this
+// kernel was slower than the unpipelined one). Nothing a barrier of this kernel separates goes through global memory.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ int clog2(int x) {
+    int l = 0;
+    while ((1 << l) < x) l++;
+    return l;
+}
+
+template <int H, int W>
+struct Cfg {
+    static constexpr int MAXD = H > W ? H : W;
+    static constexpr int P = MAXD <= 32 ? 2048 : 4096;  // sample positions per channel and work item
+    static constexpr int NB = P / (H * W);               // varblocks per work item
+    static constexpr int LD = W + 1;                     // row stride of a block image (odd: rows hit different banks)
+    static constexpr int IMG0 = H * LD;
+    // consecutive blocks of a column-pass wave land on consecutive bank ranges: image size == W (mod 32) for W < 32
+    static constexpr int IMG = W >= 32 ? IMG0 : IMG0 + ((W - IMG0 % 32) + 32) % 32;
+    static constexpr int GPB = H * W / 4;                // 4-sample groups per block
+    static constexpr int NG = P / 4 / 256;               // groups per lane and channel: 2 or 4
+    static constexpr int CH_COL = 256 / (NB * W), KC_COL = H / CH_COL;  // column pass: lane groups per column, outputs per lane
+    static constexpr int CH_ROW = 256 / (NB * H), KC_ROW = W / CH_ROW;
+    static constexpr int DSH = H / 8, DSW = W / 8;       // dctSelect size = LLF corner
+    static constexpr int PER_B = 3 * DSH * DSW;          // LLF coefficients per block
+    static constexpr int NLLF = NB * PER_B;              // ... per item (<= 192)
+    static_assert(NB >= 1 && NB * W >= 64 && NB * H >= 64, "lane groups of a pass are whole waves");
+    static_assert(KC_COL == 8 || KC_COL == 16, "8 or 16 outputs per lane");
+    static_assert(KC_ROW == 8 || KC_ROW == 16, "8 or 16 outputs per lane");
+    static_assert(NLLF <= 256, "one LLF coefficient per lane");
+};
+
+// KC outputs of one 1-D IDCT for three channels at once: lo[j] = outputs (2j, 2j+1) of the lane's low run, hi[j] = their
+// mirror images (see MirrorAcc in k_idct.hip)
+template <int KC>
+struct Acc3 {
+    v2f lo[3][KC / 4], hi[3][KC / 4];
+    __device__ __forceinline__ void init(float a, float b, float c) {
+#pragma unroll
+        for (int j = 0; j < KC / 4; j++) {
+            lo[0][j] = hi[0][j] = v2f{a, a};
+            lo[1][j] = hi[1][j] = v2f{b, b};
+            lo[2][j] = hi[2][j] = v2f{c, c};
+        }
+    }
+    // output i of channel ch: i < KC/2 counts up through the low run, i >= KC/2 continues through the mirrored run so
+    // that get(KC-1-i) is the mirror of get(i)
+    __device__ __forceinline__ float get(int ch, int i) const {
+        if (i < KC / 2) return (i & 1) ? lo[ch][i / 2].y : lo[ch][i / 2].x;
+        const int m = KC - 1 - i;
+        return (m & 1) ? hi[ch][m / 2].y : hi[ch][m / 2].x;
+    }
+};
+
+// U = 4 steps of the three-channel MAC loop: their LUT slices (scalar registers) and sample triples
+template <int KC>
+struct Blk {
+    v2f l[4][KC / 4];
+    float s[4][3];
+};
+template <int KC>
+__device__ __forceinline__ void load_blk(Blk<KC>& b, cfloatp lut /* row n0-1, the lane group's slice */, int N, const float* p0,
+                                         const float* p1, const float* p2, int stride) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const cv2fp lr = (cv2fp)(lut + u * N);
+#pragma unroll
+        for (int j = 0; j < KC / 4; j++) b.l[u][j] = lr[j];
+        b.s[u][0] = p0[u * stride];
+        b.s[u][1] = p1[u * stride];
+        b.s[u][2] = p2[u * stride];
+    }
+}
+// steps n0 .. n0+3 (n0 even): even steps add to the mirrored half, odd steps subtract
+template <int KC>
+__device__ __forceinline__ void mac_blk(Acc3<KC>& acc, const Blk<KC>& b) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const v2f s[3] = {v2f{b.s[u][0], b.s[u][0]}, v2f{b.s[u][1], b.s[u][1]}, v2f{b.s[u][2], b.s[u][2]}};
+#pragma unroll
+        for (int j = 0; j < KC / 4; j++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const v2f p = s[ch] * b.l[u][j];
+                acc.lo[ch][j] = acc.lo[ch][j] + p;
+                acc.hi[ch][j] = (u & 1) ? acc.hi[ch][j] - p : acc.hi[ch][j] + p;
+            }
+    }
+}
+// MathHelper.inverseDCTHorizontal (MathHelper.java:68-78) for the lane's KC outputs of three channels: dest = src[0], then
+// n = 1 .. N-1 in order. Steps 1..3 first, then whole blocks of 4 with the NEXT block's LUT slices and samples requested
+// before the current block's arithmetic: the scalar loads and the LDS reads share one counter (lgkmcnt) and scalar loads
+// return out of order, so a wait for either is a wait for everything outstanding -- with one block in flight behind 72
+// (144) packed operations that wait is already satisfied.
+template <int KC, int N>
+__device__ __forceinline__ void idct1d3(Acc3<KC>& acc, cfloatp lut /* row 0, lane group's slice */, const float* p0, const float* p1,
+                                        const float* p2, int stride) {
+    acc.init(p0[0], p1[0], p2[0]);
+    {
+        float s[3][3];
+        v2f l[3][KC / 4];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const cv2fp lr = (cv2fp)(lut + u * N);
+#pragma unroll
+            for (int j = 0; j < KC / 4; j++) l[u][j] = lr[j];
+            s[u][0] = p0[(u + 1) * stride];
+            s[u][1] = p1[(u + 1) * stride];
+            s[u][2] = p2[(u + 1) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const v2f sv[3] = {v2f{s[u][0], s[u][0]}, v2f{s[u][1], s[u][1]}, v2f{s[u][2], s[u][2]}};
+#pragma unroll
+            for (int j = 0; j < KC / 4; j++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const v2f p = sv[ch] * l[u][j];
+                    acc.lo[ch][j] = acc.lo[ch][j] + p;
+                    acc.hi[ch][j] = (u & 1) ? acc.hi[ch][j] + p : acc.hi[ch][j] - p;  // n = u + 1: odd n subtracts
+                }
+        }
+    }
+    if (N > 4) {
+        Blk<KC> cur;
+        load_blk<KC>(cur, lut + 3 * N, N, p0 + 4 * stride, p1 + 4 * stride, p2 + 4 * stride, stride);
+#pragma unroll 1
+        for (int n0 = 4; n0 < N; n0 += 4) {
+            Blk<KC> nxt;
+            if (n0 + 4 < N)
+                load_blk<KC>(nxt, lut + (n0 + 3) * N, N, p0 + (n0 + 4) * stride, p1 + (n0 + 4) * stride, p2 + (n0 + 4) * stride, stride);
+            mac_blk<KC>(acc, cur);
+            cur = nxt;
+        }
+    }
+}
+
+// One LLF coefficient (ky, kx) of channel plane lfp (patch origin, stride bw): forwardDCT2D of the DSH x DSW LF patch
+// (MathHelper.java:124-136: rows, then columns) times llfScale (HFCoefficients.java:194-229). Every lane recomputes the
+// row-pass values it needs: same operations in the same order as the reference's shared scratch arrays.
+template <int DSH, int DSW>
+__device__ __forceinline__ float llf_coeff3(const float* __restrict__ lut_all, const float* __restrict__ lfp, int bw, int ky, int kx) {
+    const float* lutw = lut_all + lut_off(clog2(DSW));
+    const float* luth = lut_all + lut_off(clog2(DSH));
+    const float invw = 1.0f / (float)DSW, invh = 1.0f / (float)DSH;
+    float r[DSH];
+#pragma unroll
+    for (int y = 0; y < DSH; y++) {
+        const float* row = lfp + (int64_t)y * bw;
+        float d2;
+        if (kx == 0) {
+            d2 = row[0];
+#pragma unroll
+            for (int x = 1; x < DSW; ++x) d2 = d2 + row[x];
+        } else {
+            const float* lut = lutw + (kx - 1) * DSW;
+            d2 = row[0] * lut[0];
+#pragma unroll
+            for (int n = 1; n < DSW; ++n) d2 = d2 + row[n] * lut[n];
+        }
+        r[y] = d2 * invw;
+    }
+    float d2;
+    if (ky == 0) {
+        d2 = r[0];
+#pragma unroll
+        for (int y = 1; y < DSH; ++y) d2 = d2 + r[y];
+    } else {
+        const float* lut = luth + (ky - 1) * DSH;
+        d2 = r[0] * lut[0];
+#pragma unroll
+        for (int n = 1; n < DSH; ++n) d2 = d2 + r[n] * lut[n];
+    }
+    constexpr int yll = DSH <= 1 ? 0 : DSH <= 2 ? 1 : DSH <= 4 ? 2 : 3;
+    constexpr int xll = DSW <= 1 ? 0 : DSW <= 2 ? 1 : DSW <= 4 ? 2 : 3;
+    return (d2 * invh) * (kLlfScale3[ky << (5 - yll)] * kLlfScale3[kx << (5 - xll)]);
+}
+
+// ---- work items ---------------------------------------------------------------------------------------------------
+// uniform description of one item (all scalar)
+struct Item {
+    int type;   // TransformType.type; -1: none
+    int first;  // first block record
+    int nb;     // blocks of the item
+};
+
+template <int P>
+__device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
+    Item it{-1, 0, 0};
+    if (gi >= a.total_items) return it;
+    int k = 0;
+    while (k + 1 < a.n_seg && gi >= a.seg[k + 1].item_base) k++;
+    const Wg3Seg sg = a.seg[k];
+    const int li = gi - sg.item_base;
+    const int NB = P / ((int)JXL_TT[sg.type].ph * (int)JXL_TT[sg.type].pw);
+    it.type = sg.type;
+    it.first = sg.first_block + li * NB;
+    it.nb = min(NB, sg.n_blocks - li * NB);
+    return it;
+}
+
+// what a lane holds of an item between its prefetch and its dequantisation
+template <int NG>
+struct Raw {
+    v4i q[NG][3];          // quantised coefficients of 4 consecutive x, channels X, Y, B
+    v4f w[NG == 2 ? 1 : NG][3];  // their reciprocal weights ((flip ? transposed : plain) table row); with 2048 positions per
+                           // item a block has at most 256 groups, so both groups of a lane sit at the same place of their blocks
+    float kx[NG], kb[NG];  // CfL factors of the group's 64x64 tile (0 where the reference's cache reads 0)
+    float hfm[NG];         // (float)hfMultiplier of the group's block
+    float llf;             // lanes < NLLF: one LLF coefficient of the item (finalizeLLF, from the llf planes)
+    uint32_t ok;           // bit j: group j belongs to a block of the item
+};
+
+// block records the prefetch of an item will need: its groups' blocks and (lanes < NLLF) the block of its LLF coefficient
+template <int NG>
+struct Recs {
+    v4i g[NG];
+    v4i l;
+};
+
+template <int NG>
+__device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int tid, Recs<NG>& rc) {
+    const int H = JXL_TT[it.type < 0 ? 0 : it.type].ph, W = JXL_TT[it.type < 0 ? 0 : it.type].pw;
+    const int lgGPB = __builtin_ctz(H) + __builtin_ctz(W) - 2;
+    const int per_b = 3 * (H >> 3) * (W >> 3);
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        rc.g[j] = v4i{0, 0, 0, 1};
+        const int b = (tid + 256 * j) >> lgGPB;
+        if (it.type >= 0 && b < it.nb) rc.g[j] = ((cv4ip)a.blocks)[it.first + b];
+    }
+    rc.l = v4i{0, 0, 0, 1};
+    const int bl = tid / per_b;
+    if (it.type >= 0 && bl < it.nb) rc.l = ((cv4ip)a.blocks)[it.first + bl];
+}
+
+// issue every load of item `it` this lane will need at dequantisation time (type-generic: run-time geometry)
+template <int NG>
+__device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int tid, const Recs<NG>& rc, Raw<NG>& raw) {
+    const DevFrame& f = a.f;
+    raw.ok = 0;
+    raw.llf = 0.0f;
+    const int H = JXL_TT[it.type < 0 ? 0 : it.type].ph, W = JXL_TT[it.type < 0 ? 0 : it.type].pw;
+    const int lgW4 = __builtin_ctz(W) - 2, lgGPB = __builtin_ctz(H) + lgW4;
+    const int PI = JXL_TT[it.type < 0 ? 0 : it.type].param_index;
+    const float* wtab = (H >= W ? f.weights_t : f.weights);  // TransformType.flip() for METHOD_DCT: tall or square
+    const float* wt[3] = {wtab + f.woffs[PI * 3], wtab + f.woffs[PI * 3 + 1], wtab + f.woffs[PI * 3 + 2]};
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        const int g = tid + 256 * j;
+        const int b = g >> lgGPB, r = g & ((1 << lgGPB) - 1);
+        const int n = r >> lgW4, x4 = (r & ((1 << lgW4) - 1)) << 2;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            raw.q[j][c] = v4i{0, 0, 0, 0};
+            if (NG > 2 || j == 0) raw.w[NG == 2 ? 0 : j][c] = *reinterpret_cast<const v4f*>(wt[c] + r * 4);  // row-major [n][x]: n * W + x4 = 4 r
+        }
+        raw.kx[j] = raw.kb[j] = 0.0f;
+        raw.hfm[j] = 1.0f;
+        if (it.type >= 0 && b < it.nb) {
+            const v4i rec = rc.g[j];  // DevBlock
+            const int cy = (int)((uint32_t)rec.x & 0xffffu), cx = (int)((uint32_t)rec.x >> 16);
+            const uint32_t cfl_zero = (uint32_t)rec.z;
+            raw.hfm[j] = (float)rec.w;
+            const int py = cy * 8 + n, px = cx * 8 + x4;
+            const int64_t off = (int64_t)py * f.width + px;
+#pragma unroll
+            for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const v4i*>(f.coeff[c] + off);
+            // chromaFromLuma factors of the tile this group lies in (4 consecutive x from a multiple of 4 never cross a
+            // 64-px boundary), honouring the reference's per-group cache order (DevBlock::cfl_zero)
+            const int ty = py >> 6, tx = px >> 6;
+            const int bit = (ty - ((cy * 8) >> 6)) * 5 + (tx - ((cx * 8) >> 6));
+            if (!((cfl_zero >> bit) & 1u)) {
+                raw.kx[j] = f.kx_tab[ty * f.tw + tx];
+                raw.kb[j] = f.kb_tab[ty * f.tw + tx];
+            }
+            raw.ok |= 1u << j;
+        }
+    }
+    // finalizeLLF result (k_llf_wg3 wrote it into the block's own cells of the llf planes): lane t < nb * PER_B holds
+    // coefficient (c, ky, kx) = t % PER_B of block t / PER_B
+    const int dsh = H >> 3, dsw = W >> 3, per_b = 3 * dsh * dsw;
+    const int bl = tid / per_b;
+    if (it.type >= 0 && bl < it.nb) {
+        const int rr = tid - bl * per_b, c = rr / (dsh * dsw), k = rr - c * (dsh * dsw);
+        const int ky = k / dsw, kx = k - ky * dsw;
+        const int cy = (int)((uint32_t)rc.l.x & 0xffffu), cx = (int)((uint32_t)rc.l.x >> 16);
+        raw.llf = f.llf[c][(int64_t)(cy + ky) * f.bw + cx + kx];
+    }
+}
+
+template <int H, int W, int TYPE>
+struct Body {
+    using C = Cfg<H, W>;
+
+    // ---- A. dequantise + chroma-from-luma -> LDS
+    static __device__ __forceinline__ void dequant(const Wg3Args& a, const Item& it, int tid, const Raw<C::NG>& raw, float* __restrict__ img,
+                                                   const float* __restrict__ qtab) {
+        const DevFrame& f = a.f;
+        const float qbn = f.quant_bias_numerator;
+#pragma unroll
+        for (int j = 0; j < C::NG; j++) {
+            if (!((raw.ok >> j) & 1u)) continue;
+            const int g = tid + 256 * j;
+            const int b = g / C::GPB, r = g % C::GPB;
+            const int n = r / (W / 4), x4 = (r % (W / 4)) * 4;
+            // scaleFactor[c] / hfMultiplier (HFCoefficients.java:299)
+            const float sf[3] = {f.scale_factor[0] / raw.hfm[j], f.scale_factor[1] / raw.hfm[j], f.scale_factor[2] / raw.hfm[j]};
+            // (element access by constant index after unrolling: copying the vectors into local arrays made the compiler load
+            // them as one <12 x float> and keep the whole prefetch state in scratch memory)
+#define QV(c, i) (raw.q[j][c][i])
+#define WV(c, i) (raw.w[C::NG == 2 ? 0 : j][c][i])
+            // HFCoefficients.dequantizeHFCoefficients inner expression (:309-315) through the tables: tab[a] = 0, quantBias,
+            // (float)a - qbn / (float)a for a = 0, 1, 2..63, applied with the sign of q ((float)q - qbn / (float)q ==
+            // -((float)|q| - qbn / (float)|q|) for q < 0 exactly: IEEE negation commutes with round-to-nearest division and
+            // subtraction). One branch per group for the rare |q| >= 64 instead of one per sample.
+            float dq[3][4];
+            int big = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int qv = QV(c, i);
+                    const int aq = qv < 0 ? -qv : qv;
+                    big |= aq;
+                    const float m = qtab[c * 64 + (aq & 63)];
+                    dq[c][i] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, m) ^ ((uint32_t)qv & 0x80000000u));
+                }
+            if ((uint32_t)big >= 64u) {
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int qv = QV(c, i);
+                        const int aq = qv < 0 ? -qv : qv;
+                        if (aq >= 64) dq[c][i] = (float)qv - qbn / (float)qv;
+                    }
+            }
+            float* d0 = img + (0 * C::NB + b) * C::IMG + n * C::LD + x4;
+            float* d1 = img + (1 * C::NB + b) * C::IMG + n * C::LD + x4;
+            float* d2 = img + (2 * C::NB + b) * C::IMG + n * C::LD + x4;
+            // the LLF corner (dctSelect size) is skipped by the dequantiser (:305-306), reads 0 in chromaFromLuma and is
+            // overwritten by finalizeLLF (:194-229): those samples are written by the LLF lanes below
+            const bool corner_row = n < C::DSH;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float dy = dq[1][i] * sf[1] * WV(1, i);
+                const float dx = dq[0][i] * sf[0] * WV(0, i) + raw.kx[j] * dy;  // chromaFromLuma (:186-188)
+                const float db = dq[2][i] * sf[2] * WV(2, i) + raw.kb[j] * dy;
+                if (i < C::DSW && corner_row && x4 + i < C::DSW) continue;
+                d0[i] = dx;
+                d1[i] = dy;
+                d2[i] = db;
+            }
+#undef QV
+#undef WV
+        }
+        if (tid < C::NLLF) {
+            const int b = tid / C::PER_B, rr = tid % C::PER_B;
+            if (b < it.nb) {
+                const int c = rr / (C::DSH * C::DSW), k = rr % (C::DSH * C::DSW);
+                img[(c * C::NB + b) * C::IMG + (k / C::DSW) * C::LD + (k % C::DSW)] = raw.llf;
+            }
+        }
+    }
+
+    // ---- B + C. column pass (in place), row pass -> frame planes
+    static __device__ __forceinline__ void passes(const Wg3Args& a, const Item& it, int tid, float* __restrict__ img, int it_no) {
+        (void)it_no;
+        const DevFrame& f = a.f;
+        const cfloatp lut_h = (cfloatp)(f.lut + lut_off(clog2(H)));
+        const cfloatp lut_w = (cfloatp)(f.lut + lut_off(clog2(W)));
+        const int cidx = tid % (C::NB * W), kc_col = __builtin_amdgcn_readfirstlane(tid / (C::NB * W));
+        const int cb = cidx / W, cxx = cidx % W;
+        const int ridx = tid % (C::NB * H), kc_row = __builtin_amdgcn_readfirstlane(tid / (C::NB * H));
+        const int rb = ridx / H, ry = ridx % H;
+        // block of this lane's row (row pass output address): requested now, needed two barriers later
+        v4i rrec = v4i{0, 0, 0, 0};
+        if (rb < it.nb) rrec = ((cv4ip)a.blocks)[it.first + rb];
+        {
+            constexpr int KC = C::KC_COL;
+            Acc3<KC> acc;
+            float* d0 = img + (0 * C::NB + cb) * C::IMG + cxx;
+            float* d1 = img + (1 * C::NB + cb) * C::IMG + cxx;
+            float* d2 = img + (2 * C::NB + cb) * C::IMG + cxx;
+            idct1d3<KC, H>(acc, lut_h + kc_col * (KC / 2), d0, d1, d2, C::LD);
+            STAMP3(4);
+            lds_barrier();
+            STAMP3(5);
+            float* d[3] = {d0, d1, d2};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int i = 0; i < KC / 2; i++) {
+                    d[ch][(kc_col * (KC / 2) + i) * C::LD] = acc.get(ch, i);
+                    d[ch][(H - 1 - kc_col * (KC / 2) - i) * C::LD] = acc.get(ch, KC - 1 - i);
+                }
+        }
+        lds_barrier();
+        STAMP3(6);
+        {
+            constexpr int KC = C::KC_ROW;
+            Acc3<KC> acc;
+            const float* r0 = img + (0 * C::NB + rb) * C::IMG + ry * C::LD;
+            const float* r1 = img + (1 * C::NB + rb) * C::IMG + ry * C::LD;
+            const float* r2 = img + (2 * C::NB + rb) * C::IMG + ry * C::LD;
+            idct1d3<KC, W>(acc, lut_w + kc_row * (KC / 2), r0, r1, r2, 1);
+            STAMP3(7);
+            if (rb < it.nb) {
+                float* o3[3] = {a.o0, a.o1, a.o2};
+                const int cy = (int)((uint32_t)rrec.x & 0xffffu), cx = (int)((uint32_t)rrec.x >> 16);
+                const int64_t off = (int64_t)(cy * 8 + ry) * f.width + cx * 8;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    // two runs of KC/2 consecutive outputs: the low one ascending, the mirrored one ending at W-1-kc*KC/2
+                    float* olo = o3[ch] + off + kc_row * (KC / 2);
+                    float* ohi = o3[ch] + off + W - (kc_row + 1) * (KC / 2);
+#pragma unroll
+                    for (int kk = 0; kk < KC / 2; kk += 4) {
+                        *reinterpret_cast<float4*>(olo + kk) = make_float4(acc.get(ch, kk), acc.get(ch, kk + 1), acc.get(ch, kk + 2), acc.get(ch, kk + 3));
+                        *reinterpret_cast<float4*>(ohi + kk) = make_float4(acc.get(ch, KC / 2 + kk), acc.get(ch, KC / 2 + kk + 1),
+                                                                           acc.get(ch, KC / 2 + kk + 2), acc.get(ch, KC / 2 + kk + 3));
+                    }
+                }
+            }
+        }
+        STAMP3(8);
+    }
+};
+
+// type dispatch of the two specialised phases (workgroup-uniform scalar branch)
+template <bool BIG, int NG>
+__device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int tid, const Raw<NG>& raw, float* img, const float* qtab) {
+    if constexpr (BIG) {
+        switch (it.type) {
+        case 18: Body<64, 64, 18>::dequant(a, it, tid, raw, img, qtab); break;
+        case 19: Body<64, 32, 19>::dequant(a, it, tid, raw, img, qtab); break;
+        case 20: Body<32, 64, 20>::dequant(a, it, tid, raw, img, qtab); break;
+        default: break;
+        }
+    } else {
+        switch (it.type) {
+        case 0: Body<8, 8, 0>::dequant(a, it, tid, raw, img, qtab); break;
+        case 4: Body<16, 16, 4>::dequant(a, it, tid, raw, img, qtab); break;
+        case 5: Body<32, 32, 5>::dequant(a, it, tid, raw, img, qtab); break;
+        case 6: Body<16, 8, 6>::dequant(a, it, tid, raw, img, qtab); break;
+        case 7: Body<8, 16, 7>::dequant(a, it, tid, raw, img, qtab); break;
+        case 8: Body<32, 8, 8>::dequant(a, it, tid, raw, img, qtab); break;
+        case 9: Body<8, 32, 9>::dequant(a, it, tid, raw, img, qtab); break;
+        case 10: Body<32, 16, 10>::dequant(a, it, tid, raw, img, qtab); break;
+        case 11: Body<16, 32, 11>::dequant(a, it, tid, raw, img, qtab); break;
+        default: break;
+        }
+    }
+}
+template <bool BIG>
+__device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int tid, float* img, int it_no) {
+    if constexpr (BIG) {
+        switch (it.type) {
+        case 18: Body<64, 64, 18>::passes(a, it, tid, img, it_no); break;
+        case 19: Body<64, 32, 19>::passes(a, it, tid, img, it_no); break;
+        case 20: Body<32, 64, 20>::passes(a, it, tid, img, it_no); break;
+        default: break;
+        }
+    } else {
+        switch (it.type) {
+        case 0: Body<8, 8, 0>::passes(a, it, tid, img, it_no); break;
+        case 4: Body<16, 16, 4>::passes(a, it, tid, img, it_no); break;
+        case 5: Body<32, 32, 5>::passes(a, it, tid, img, it_no); break;
+        case 6: Body<16, 8, 6>::passes(a, it, tid, img, it_no); break;
+        case 7: Body<8, 16, 7>::passes(a, it, tid, img, it_no); break;
+        case 8: Body<32, 8, 8>::passes(a, it, tid, img, it_no); break;
+        case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no); break;
+        case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no); break;
+        case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no); break;
+        default: break;
+        }
+    }
+}
+
+}  // namespace
+
+// Persistent kernel: workgroup w handles the items w, w + G, w + 2G, ... (G = grid) of the launch's item list (segments in
+// launch order, costliest type first: consecutive items go to different workgroups and every workgroup gets an equal share
+// of every type). Dynamic hand-out through an atomic ticket counter was built and measured, and lost: one ticket per item on
+// one address runs at the chip-wide ~90 atomics per microsecond (a 4000-item launch twice as slow), four tickets per atomic
+// leave up to four items of imbalance at the tail (same loss). The grid is sized to be resident at once instead.
+// Two instantiations by register / LDS class: BIG = the 64-point family (4096 positions per item: 50 KB of LDS, 4 groups
+// per lane), !BIG = everything up to 32 points (2048 positions: <= 34 KB).
+#ifndef WG3_SMALL_OCC
+#define WG3_SMALL_OCC 3
+#endif
+template <bool BIG>
+__global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const Wg3Args a) {
+    constexpr int P = BIG ? 4096 : 2048, NG = P / 4 / 256;
+    extern __shared__ float lds[];
+    const int tid0 = threadIdx.x;
+    const int G = (int)gridDim.x;
+    int gi = (int)blockIdx.x;
+    Item cur = item_of<P>(a, gi);
+    if (cur.type < 0) return;
+    float* img = lds;
+    float* qtab = lds + a.img_floats;  // [3][64]: 0, quantBias[c], (float)a - qbn / (float)a
+    if (tid0 < 192) {
+        const int c = tid0 >> 6, aq = tid0 & 63;
+        qtab[tid0] = aq == 0 ? 0.0f : aq == 1 ? a.f.quant_bias[c] : (float)aq - a.f.quant_bias_numerator / (float)aq;
+    }
+    Raw<NG> raw;
+    Recs<NG> rc;
+    load_recs<NG>(a, cur, tid0, rc);
+    prefetch<NG>(a, cur, tid0, rc, raw);
+    Item nxt = item_of<P>(a, gi + G);
+    load_recs<NG>(a, nxt, tid0, rc);
+    lds_barrier();  // qtab
+    int it_no = 0;
+#pragma unroll 1
+    for (;;) {
+        STAMP3(0);
+        // the lane index is made opaque once per item: otherwise the optimiser hoists the lane-dependent address arithmetic
+        // of ALL type cases out of the item loop (some 80 loop-invariant VGPRs) and spills it
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        do_dequant<BIG, NG>(a, cur, tid, raw, img, qtab);  // the loads were issued one item ago
+        STAMP3(1);
+        lds_barrier();
+        STAMP3(2);
+        // everything the next item needs from memory: in flight during both passes of this one. Its block records were
+        // requested one item earlier still, so no load here waits for another.
+        prefetch<NG>(a, nxt, tid, rc, raw);
+        gi += G;
+        const Item nn = item_of<P>(a, gi + G);
+        load_recs<NG>(a, nn, tid, rc);
+        STAMP3(3);
+        do_passes<BIG>(a, cur, tid, img, it_no);
+        if (nxt.type < 0) break;
+        cur = nxt;
+        nxt = nn;
+        STAMP3(9);
+        lds_barrier();  // every lane has read the image before the next item's samples overwrite it
+        STAMP3(10);
+        it_no++;
+    }
+}
+
+// finalizeLLF (HFCoefficients.java:194-229) of every block of the launch's segments, one lane per coefficient, written over
+// the block's own cells of the llf planes (a block covers exactly dctSelectHeight x dctSelectWidth cells)
+template <int H, int W>
+__device__ __forceinline__ void llf_one(const Wg3Args& a, const Wg3Seg& sg, int t, float* l0, float* l1, float* l2) {
+    constexpr int DSH = H / 8, DSW = W / 8, PER_B = 3 * DSH * DSW;
+    const int b = t / PER_B, rr = t % PER_B;
+    if (b >= sg.n_blocks) return;
+    const int c = rr / (DSH * DSW), k = rr % (DSH * DSW);
+    const v4i rec = ((cv4ip)a.blocks)[sg.first_block + b];
+    const int cy = (int)((uint32_t)rec.x & 0xffffu), cx = (int)((uint32_t)rec.x >> 16);
+    const float v = llf_coeff3<DSH, DSW>(a.f.lut, a.f.lf[c] + (int64_t)cy * a.f.bw + cx, a.f.bw, k / DSW, k % DSW);
+    (c == 0 ? l0 : c == 1 ? l1 : l2)[(int64_t)(cy + k / DSW) * a.f.bw + cx + k % DSW] = v;
+}
+
+__global__ __launch_bounds__(256) void k_llf_wg3(const Wg3Args a, float* l0, float* l1, float* l2) {
+    int t = (int)(blockIdx.x * 256 + threadIdx.x);
+    for (int k = 0; k < a.n_seg; k++) {
+        const Wg3Seg sg = a.seg[k];
+        // (the LLF of an 8x8 block is its LF sample: the llf planes start as a copy of the lf planes)
+        const int n = sg.type == 0 ? 0 : sg.n_blocks * 3 * (JXL_TT[sg.type].ph / 8) * (JXL_TT[sg.type].pw / 8);
+        if (t < n) {
+            switch (sg.type) {
+            case 4: llf_one<16, 16>(a, sg, t, l0, l1, l2); break;
+            case 5: llf_one<32, 32>(a, sg, t, l0, l1, l2); break;
+            case 6: llf_one<16, 8>(a, sg, t, l0, l1, l2); break;
+            case 7: llf_one<8, 16>(a, sg, t, l0, l1, l2); break;
+            case 8: llf_one<32, 8>(a, sg, t, l0, l1, l2); break;
+            case 9: llf_one<8, 32>(a, sg, t, l0, l1, l2); break;
+            case 10: llf_one<32, 16>(a, sg, t, l0, l1, l2); break;
+            case 11: llf_one<16, 32>(a, sg, t, l0, l1, l2); break;
+            case 18: llf_one<64, 64>(a, sg, t, l0, l1, l2); break;
+            case 19: llf_one<64, 32>(a, sg, t, l0, l1, l2); break;
+            case 20: llf_one<32, 64>(a, sg, t, l0, l1, l2); break;
+            default: break;
+            }
+            return;
+        }
+        t -= n;
+    }
+}
+
+#ifdef JXL_STAMPS
+extern "C" int jxl_debug_set_stamps3(void* dev_ptr) {
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps3), &p, sizeof p);
+}
+#endif
+
+bool wg3_handles(int type) {
+    switch (type) {
+    case 0: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 18: case 19: case 20: return true;
+    default: return false;
+    }
+}
+bool wg3_big(int type) { return type == 18 || type == 19 || type == 20; }
+
+int wg3_blocks_per_item(int type) {
+    const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
+    return ((h > w ? h : w) <= 32 ? 2048 : 4096) / (h * w);
+}
+
+// floats of the three-channel LDS image of a type
+static int wg3_img_floats(int type) {
+    const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
+    const int nb = wg3_blocks_per_item(type);
+    const int img0 = h * (w + 1);
+    const int img = w >= 32 ? img0 : img0 + ((w - img0 % 32) + 32) % 32;
+    return 3 * nb * img;
+}
+
+// Fills the argument block for the frame's types of one register class (which = 0: up to 32 points, 1: the 64-point family;
+// 2: both, for the LLF launch), in the given launch order. Returns the number of items (0: nothing to launch).
+int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],
+                   Wg3Args& a) {
+    a.f = f;
+    a.blocks = blocks;
+    a.o0 = out[0]; a.o1 = out[1]; a.o2 = out[2];
+    a.n_seg = 0;
+    a.total_items = 0;
+    a.img_floats = 0;
+    for (int i = 0; i < n_seg && a.n_seg < Wg3Args::kMaxSeg; i++) {
+        if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
+        Wg3Seg& sg = a.seg[a.n_seg++];
+        const int nb = wg3_blocks_per_item(segs[i].type);
+        sg.type = segs[i].type;
+        sg.first_block = segs[i].first_block;
+        sg.n_blocks = segs[i].n_blocks;
+        sg.item_base = a.total_items;
+        a.total_items += (segs[i].n_blocks + nb - 1) / nb;
+        a.img_floats = std::max(a.img_floats, wg3_img_floats(segs[i].type));
+    }
+    return a.total_items;
+}
+
+// LLF coefficients of the class's blocks into the llf planes (must precede launch_idct_wg3 on the same stream)
+void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s) {
+    int64_t n = 0;
+    for (int k = 0; k < a.n_seg; k++)
+        if (a.seg[k].type != 0) n += (int64_t)a.seg[k].n_blocks * 3 * (JXL_TT[a.seg[k].type].ph / 8) * (JXL_TT[a.seg[k].type].pw / 8);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_llf_wg3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, llf[0], llf[1], llf[2]);
+}
+
+// grid_cap: workgroups to launch at most (persistent; never more than there are items)
+void launch_idct_wg3(const Wg3Args& a, bool big, int grid_cap, hipStream_t s) {
+    if (a.total_items <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_wg3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_wg3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    const size_t lds = sizeof(float) * ((size_t)a.img_floats + 3 * 64);
+    const int grid = std::max(1, std::min(a.total_items, grid_cap));
+    if (big) hipLaunchKernelGGL(k_idct_wg3<true>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_idct_wg3<false>, dim3(grid), dim3(256), lds, s, a);
+}
+
+}  // namespace jxl

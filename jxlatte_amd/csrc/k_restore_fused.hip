@@ -650,15 +650,18 @@ __global__ JXL_RESTORE_BOUNDS(ITERS, 1) void k_restore_fused_batch(const FusedAr
 template <bool GAB, int ITERS, bool PLAIN, int PH>
 void launch_tph(const FusedArgs& a, hipStream_t s) {
     using G = Geo<GAB, ITERS>;
+    // experiment knob: extra dynamic LDS per workgroup caps the workgroups per CU (160 KiB / size), leaving wave slots to
+    // the latency-bound IDCT kernels of other frames in a batch
+    static const size_t pad = getenv("JXL_RESTORE_LDS_PAD") ? (size_t)atoi(getenv("JXL_RESTORE_LDS_PAD")) : 0;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused<GAB, ITERS, PLAIN, PH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_BYTES + pad));
         attr_set = true;
     }
     const int n_tiles = ((a.W + G::OW - 1) / G::OW) * ((a.H + G::OH - 1) / G::OH);
     const dim3 grid(((n_tiles + 7) / 8) * 8);
-    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, a);
 }
 template <bool GAB, int ITERS, bool PLAIN>
 void launch_tp(const FusedArgs& a, hipStream_t s) {
