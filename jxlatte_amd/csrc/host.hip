@@ -83,6 +83,7 @@ struct jxl_ctx {
     struct LfJob { jxl_lfquant_desc d; std::vector<int32_t> q[3]; };
     std::vector<LfJob> lf_jobs;  // integer LF images to dequantise + smooth on the device (row f1)
     DevBuf lfq_tmp[3];
+    DevBuf pq_tab;  // PQ segment table (jxl_fastpow.h), uploaded at context creation
     // binned work
     // one merged launch: the segments (types) of one register class; channel >= 0: chroma-subsampled frame, one channel per launch
     struct TypeLaunch { int cls, channel; std::vector<IdctSegment> segs; };
@@ -388,6 +389,12 @@ void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
 
 const float kStepMultiplier = 1.65f * 4.0f * (1.0f - (float)std::sqrt(0.5));  // Frame.java:545
 
+// TF_PQ.fromLinear (TransferFunction.java:83-87) in long double, with the reference's constants
+long double pq_ld(long double x) {
+    const long double d = powl(x, 0.159423828125L);
+    return powl((0.8359375L + 18.8515625L * d) / (1.0L + 18.6875L * d), 78.84375L);
+}
+
 EpfParams make_epf(const float cs[3], float pass0, float pass2, float border, int iter, float inv_sigma_modular) {
     EpfParams e;
     for (int i = 0; i < 3; i++) e.channel_scale[i] = cs[i];
@@ -408,6 +415,35 @@ XybParams make_xyb(const float m[9], const float ob[3], const float cob[3], floa
     return x;
 }
 
+}  // namespace
+
+namespace jxl {
+// The PQ segment table of jxl_fastpow.h (fp_tf_pq_tab): segment idx covers the floats whose bits >> 16 == idx + (87 << 7),
+// i.e. [x0, x0 + w) with x0 = 2^(e-127) (1 + m / 128), w = 2^(e-127) / 128; quadratic through the Chebyshev nodes of the segment
+// around its midpoint, a0 as a float pair.
+void build_pq_table(float* out) {
+    const long double cn = 0.86602540378443864676L;  // cos(pi / 6)
+    for (int i = 0; i < (129 - 87) * 128; i++) {
+        const uint32_t b0 = ((uint32_t)i + (87u << 7)) << 16;
+        float x0f, xmf;
+        const uint32_t bm = b0 | 0x00008000u;
+        memcpy(&x0f, &b0, 4);
+        memcpy(&xmf, &bm, 4);
+        const long double xm = xmf, h = (long double)xmf - (long double)x0f, tn = h * cn;
+        const long double y0 = pq_ld(xm), yp = pq_ld(xm + tn), ym = pq_ld(xm - tn);
+        const long double a1 = (yp - ym) / (2.0L * tn), a2 = (yp + ym - 2.0L * y0) / (2.0L * tn * tn);
+        const float a0hi = (float)y0;
+        out[4 * i + 0] = a0hi;
+        out[4 * i + 1] = (float)(y0 - (long double)a0hi);
+        out[4 * i + 2] = (float)a1;
+        out[4 * i + 3] = (float)a2;
+    }
+}
+}  // namespace jxl
+
+extern "C" void jxl_debug_pq_table(float* out) { jxl::build_pq_table(out); }  // CPU tests: the table without a device
+
+namespace {
 int out_elem_size(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 2 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 1 : 4; }
 int out_max_value(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 65535 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 255 : 0; }
 bool out_interleaved(int fmt) { return fmt == JXL_OUT_RGB8 || fmt == JXL_OUT_RGB16; }
@@ -464,6 +500,20 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
         jxl_ctx_destroy(c);
         return fail(nullptr, JXL_ERR_DEVICE, "cannot upload the cosine LUT");
     }
+    {
+        static std::vector<float> pq;  // the same for every context of the process
+        if (pq.empty()) {
+            pq.resize(kPqTableFloats);
+            build_pq_table(pq.data());
+        }
+        if (!getenv("JXL_PQ_F64")) {  // experiment knob: keep the double-precision PQ
+            if (!c->pq_tab.ensure(sizeof(float) * pq.size()) ||
+                hipMemcpy(c->pq_tab.p, pq.data(), sizeof(float) * pq.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                jxl_ctx_destroy(c);
+                return fail(nullptr, JXL_ERR_DEVICE, "cannot upload the PQ table");
+            }
+        }
+    }
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
@@ -488,6 +538,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
         c->coeff[i].release(); c->lf[i].release(); c->llf[i].release(); c->lfq_tmp[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
     }
     for (int i = 0; i < 3; i++) c->hfm_sub[i].release();
+    c->pq_tab.release();
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++)
@@ -960,6 +1011,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         }
         rp.xybp = make_xyb(p.opsin_matrix, p.opsin_bias, p.cbrt_opsin_bias, p.intensity_target);
         rp.global_scale_f = p.global_scale_f;
+        rp.pq_tab = c->pq_tab.as<float>();
         memcpy(rp.sharp_lut, p.epf_sharp_lut, sizeof rp.sharp_lut);
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
@@ -1007,7 +1059,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             const int es = out_elem_size(p.out_format);
             const bool il = out_interleaved(p.out_format);
             for (int i = 0; i < 3; i++) {
-                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer, maxv, c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0);
+                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer, maxv, c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, c->pq_tab.as<float>());
                 c->result[i] = c->outbuf[i].p;
                 launches++;
             }
@@ -1408,7 +1460,7 @@ jxl_status jxl_stage_transfer(jxl_ctx* c, const float* in, int64_t n, int32_t tr
     float* di = t.up(in, (size_t)n);
     int32_t* dout = t.up<int32_t>(nullptr, (size_t)n);
     if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
-    launch_transfer(di, n, transfer, max_value, dout, 4, c->stream);
+    launch_transfer(di, n, transfer, max_value, dout, 4, c->stream, 1, 0, c->pq_tab.as<float>());
     if ((st = finish(c))) return st;
     HIP_TRY(c, hipMemcpy(max_value > 0 ? (void*)out_i : (void*)out_f, dout, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return JXL_OK;

@@ -92,6 +92,33 @@ __device__ __forceinline__ float fp_tf_pq(float f) {
     return (float)fp_pow(fp_div(a, b), 78.84375);
 }
 
+// ---- PQ through a table: one 16-byte gather and three fused multiply-adds per sample ----------------------------------------
+// The double-precision form above costs ~110 f64 operations per sample (f64 issues at half the f32 rate): three samples per
+// pixel made the transfer stage of the 8K PQ configuration dearer than Gaborish + two EPF iterations + XYB together
+// (round-1 verdict). PQ is ONE fixed smooth function float -> float, so it is tabulated: the positive floats of [2^-40, 4) are
+// cut into 42 binades x 128 mantissa segments; per segment the host fits y(xm + t) = a0 + a1 t + a2 t^2 in long double through
+// the three Chebyshev nodes of the segment (truncation error = third derivative x h^3 / 24: 0.013 ulp; 64 segments per binade gave 0.1) and stores
+// a0 as a float pair (hi, lo), a1, a2 as floats. t = x - xm is exact (both in one binade), the correction a0lo + t (a1 + t a2)
+// is below 0.3 % of a0hi, so its float rounding is ~2^-31 relative and the only rounding that matters is the final addition:
+// the result is within 0.5 + 0.01 ulp of the true value, the reference's (float) of a double is within 0.5 ulp -> they differ
+// by at most 1 ulp (checked over ALL 2^32 float inputs on the GPU against the oracle: tools/pq_sweep.py, profiles/). Inputs
+// outside the table (zero, tiny, >= 4, negative, inf, NaN) take the double-precision form.
+constexpr int kPqExpLo = 87;   // biased exponent of 2^-40
+constexpr int kPqExpHi = 129;  // first biased exponent beyond the table (2^2)
+constexpr int kPqSegs = (kPqExpHi - kPqExpLo) * 128;
+
+__device__ __forceinline__ float fp_tf_pq_tab(float f, const float4* __restrict__ tab) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    const uint32_t idx = (b >> 16) - ((uint32_t)kPqExpLo << 7);  // sign bit set or exponent below the table: wraps to a huge value
+    if (idx < (uint32_t)kPqSegs) {
+        const float4 sg = tab[idx];
+        const float xm = __builtin_bit_cast(float, (b & 0xFFFF0000u) | 0x00008000u);  // midpoint of the segment
+        const float t = f - xm;
+        return sg.x + __builtin_fmaf(t, __builtin_fmaf(t, sg.w, sg.z), sg.y);
+    }
+    return fp_tf_pq(f);
+}
+
 // TF_SRGB.fromLinearF (TransferFunction.java:39-44)
 __device__ __forceinline__ float fp_tf_srgb(float f) {
     if (f < 0.00313066844250063f) return f * 12.92f;

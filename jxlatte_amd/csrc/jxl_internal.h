@@ -148,8 +148,12 @@ void launch_xyb(float* const planes[3], int64_t n, const XybParams& p, hipStream
 void launch_ycbcr(float* const planes[3], int64_t n, hipStream_t s);
 // transfer + quantise: out elem size 4 (float or int32), 2 (u16), 1 (u8)
 // out index = i * out_pitch + out_off (pitch 1 = planar; pitch 3, off c = pixel-interleaved)
+// pq_tab: the PQ segment table of build_pq_table (device; null: the double-precision form)
 void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s,
-                     int out_pitch = 1, int out_off = 0);
+                     int out_pitch = 1, int out_off = 0, const float* pq_tab = nullptr);
+// PQ as a table of quadratic segments (jxl_fastpow.h): kPqTableFloats floats = float4 {a0 hi, a0 lo, a1, a2} per segment
+constexpr int kPqTableFloats = (129 - 87) * 128 * 4;
+void build_pq_table(float* out /* [kPqTableFloats] */);
 // fused restoration + colour tile kernel (Gab -> EPF iters -> XYB -> optional transfer/quantise)
 struct RestoreParams {
     int gab, epf_iters, xyb, transfer, max_value, out_elem;
@@ -159,6 +163,7 @@ struct RestoreParams {
     XybParams xybp;
     float global_scale_f;
     float sharp_lut[8];
+    const float* pq_tab;  // device: PQ segment table (null: double-precision PQ)
 };
 // argument block of the fused kernel (one per frame; an array of them for the batched launch)
 struct FusedArgs {

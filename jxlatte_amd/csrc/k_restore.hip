@@ -233,7 +233,10 @@ __device__ __forceinline__ int32_t java_f2i(float v) {
     return (int32_t)v;
 }
 
-__device__ __forceinline__ float apply_transfer(float v, int transfer) {
+__device__ __forceinline__ float apply_transfer(float v, int transfer, const float4* pq_tab) {
+#ifndef JXL_EXACT_POW
+    if (transfer == JXL_TRANSFER_PQ && pq_tab) return fp_tf_pq_tab(v, pq_tab);
+#endif
     if (transfer == JXL_TRANSFER_PQ) return tf_pq(v);
     if (transfer == JXL_TRANSFER_SRGB) return tf_srgb(v);
     return v;
@@ -246,9 +249,9 @@ __device__ __forceinline__ int32_t quantise(float v, int max_value) {
 }
 
 __global__ __launch_bounds__(256) void k_transfer(const float* in, int64_t n, int transfer, int max_value, void* out,
-                                                  int out_elem, int out_pitch, int out_off) {
+                                                  int out_elem, int out_pitch, int out_off, const float4* pq_tab) {
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float v = apply_transfer(in[i], transfer);
+        const float v = apply_transfer(in[i], transfer, pq_tab);
         const int64_t o = i * out_pitch + out_off;
         if (max_value > 0) {
             const int32_t q = quantise(v, max_value);
@@ -262,11 +265,12 @@ __global__ __launch_bounds__(256) void k_transfer(const float* in, int64_t n, in
 }
 
 void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s,
-                     int out_pitch, int out_off) {
+                     int out_pitch, int out_off, const float* pq_tab) {
     if (n <= 0) return;
     int grid = (int)((n + 255) / 256);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(k_transfer, dim3(grid), dim3(256), 0, s, in, n, transfer, max_value, out, out_elem, out_pitch, out_off);
+    hipLaunchKernelGGL(k_transfer, dim3(grid), dim3(256), 0, s, in, n, transfer, max_value, out, out_elem, out_pitch, out_off,
+                       reinterpret_cast<const float4*>(pq_tab));
 }
 
 }  // namespace jxl

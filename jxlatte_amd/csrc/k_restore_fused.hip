@@ -402,6 +402,10 @@ struct OutSink {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             float t = v[c];
+#ifndef JXL_EXACT_POW
+            if (a.p.transfer == JXL_TRANSFER_PQ && a.p.pq_tab) t = fp_tf_pq_tab(t, reinterpret_cast<const float4*>(a.p.pq_tab));
+            else
+#endif
             if (a.p.transfer == JXL_TRANSFER_PQ) t = tf_pq_f(t);
             else if (a.p.transfer == JXL_TRANSFER_SRGB) t = tf_srgb_f(t);
             if (a.p.max_value > 0) {

@@ -83,3 +83,63 @@ def test_pq_and_srgb_float_results_equal_libm():
     s1 = np.power(g.astype(np.float64), 0.4166666666666667).astype(np.float32)
     s2 = fast_pow(g.astype(np.float64), 0.4166666666666667).astype(np.float32)
     assert (s1.view(np.uint32) != s2.view(np.uint32)).mean() < 1e-5
+
+
+def _pq_table():
+    import ctypes as C
+    from jxlatte_amd import _lib
+    lib = _lib.load()
+    n = (129 - 87) * 128
+    out = np.zeros((n, 4), np.float32)
+    lib.jxl_debug_pq_table.restype = None
+    lib.jxl_debug_pq_table.argtypes = [C.c_void_p]
+    lib.jxl_debug_pq_table(out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def _pq_tab_eval(x, tab):
+    """fp_tf_pq_tab of csrc/jxl_fastpow.h restated with float32 roundings (each fused multiply-add = one rounding of the
+    float64 value of t * a + b, which is exact to 2^-53)"""
+    b = x.view(np.uint32)
+    idx = (b >> np.uint32(16)).astype(np.int64) - (87 << 7)
+    assert ((idx >= 0) & (idx < len(tab))).all()
+    sg = tab[idx]
+    xm = ((b & np.uint32(0xFFFF0000)) | np.uint32(0x00008000)).view(np.float32)
+    t = (x - xm).astype(np.float32)
+    assert np.array_equal(t.astype(np.float64), x.astype(np.float64) - xm.astype(np.float64))  # exact
+    inner = (t.astype(np.float64) * sg[:, 3].astype(np.float64) + sg[:, 2].astype(np.float64)).astype(np.float32)
+    corr = (t.astype(np.float64) * inner.astype(np.float64) + sg[:, 1].astype(np.float64)).astype(np.float32)
+    return (sg[:, 0].astype(np.float64) + corr.astype(np.float64)).astype(np.float32), corr, sg
+
+
+def _pq_ld(x):
+    x = x.astype(np.longdouble)
+    d = np.power(x, np.longdouble(0.159423828125))
+    return np.power((np.longdouble(0.8359375) + np.longdouble(18.8515625) * d) / (np.longdouble(1.0) + np.longdouble(18.6875) * d),
+                    np.longdouble(78.84375))
+
+
+def test_pq_table_within_one_ulp_of_the_reference_form():
+    """the tabulated PQ (the device's fast path) on every segment: both ends, the midpoint neighbours and random members:
+    within 0.53 ulp of the long double value, hence within 1 ulp of the reference's (float) of a double pow; the GPU sweep
+    over all 2^32 inputs is tools/pq_sweep.py"""
+    tab = _pq_table()
+    rng = np.random.default_rng(3)
+    n = len(tab)
+    base = ((np.arange(n, dtype=np.uint32) + np.uint32(87 << 7)) << np.uint32(16))
+    offs = np.concatenate([np.array([0, 1, 0x7FFF, 0x8000, 0x8001, 0xFFFE, 0xFFFF], np.uint32),
+                           rng.integers(0, 1 << 16, 57, dtype=np.uint32)])
+    bits = (base[:, None] | offs[None, :]).reshape(-1)
+    x = bits.view(np.float32)
+    got, corr, sg = _pq_tab_eval(x, tab)
+    exact = _pq_ld(x)
+    ulp = np.spacing(np.abs(exact.astype(np.float32))).astype(np.longdouble)
+    err = np.abs(got.astype(np.longdouble) - exact) / ulp
+    assert float(err.max()) <= 0.53, float(err.max())
+    # the correction term is small against a0: its own rounding cannot matter
+    assert float(np.abs(corr / sg[:, 0]).max()) < 0.02
+    # against the reference's form (double pow, cast to float)
+    d = np.power(x.astype(np.float64), 0.159423828125)
+    ref = np.power((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375).astype(np.float32)
+    du = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert int(du.max()) <= 1 and float((du != 0).mean()) < 0.02

@@ -74,7 +74,7 @@ def test_c4_8k_pq_u16_vs_oracle(ctx, orc):
     assert got.shape == exp.shape == (3, 4320, 7680)
     d = np.abs(got.astype(np.int32) - exp.astype(np.int32))
     assert d.max() <= 1, "PQ u16 differs by %d code values" % d.max()
-    assert (d != 0).mean() < 1e-3, "too many off-by-one code values: %g" % (d != 0).mean()
+    assert (d != 0).mean() < 2e-3, "too many off-by-one code values: %g" % (d != 0).mean()
 
 
 def test_large_block_mix_frame(ctx, orc):

@@ -102,7 +102,11 @@ def test_transfer_within_one_ulp(ctx, orc, tf):
     got, exp = host.transfer(ctx, x, tf), orc.transfer(x, tf)
     d = ulp_diff(got, exp)
     assert d.max() <= 1, d.max()
-    assert (d != 0).mean() < 1e-3
+    # sRGB keeps the double-precision form: the float casts agree except for double results within 1e-13 of a rounding
+    # boundary. PQ inside [2^-40, 4) is the tabulated form, within 0.51 ulp of the true value: it differs from the
+    # reference's correctly rounded cast whenever the true value lies within ~0.01 ulp of a boundary, i.e. for a few per cent
+    # of the inputs, never by more than 1 ulp (all 2^32 inputs: tools/pq_sweep.py, profiles/r2_pq_sweep.txt)
+    assert (d != 0).mean() < (0.05 if tf == abi.TRANSFER_PQ else 1e-3)
     for maxv in (255, 65535):
         gq, eq = host.transfer(ctx, x, tf, maxv), orc.transfer(x, tf, maxv)
         assert np.abs(gq - eq).max() <= 1 and (gq != eq).mean() < 1e-3
