@@ -40,7 +40,9 @@ struct DevBuf {
 };
 
 struct ModOp {
-    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy, 4 batched squeeze step (bt)
+    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy, 4 batched squeeze step (bt), 5 chain of small steps (chain_*)
+    const SqueezeBatch* chain_dev = nullptr;
+    int chain_steps = 0, chain_slots = 0;
     SqueezeBatch bt;
     const int32_t* a;
     const int32_t* b;
@@ -1835,9 +1837,16 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
             if (!o.d) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze output)");
             o.original = false;
             op.a = a.d; op.b = re.d; op.o = o.d;
-            SqueezeDesc sd{a.d, re.d, o.d, op.adim, op.rdim, op.other, nullptr};
-            if (op.rdim > kSqueezeSeg && !getenv("JXL_SQUEEZE_SERIAL")) {  // segmented walk: chain state per segment start
-                sd.side = alloc((size_t)((op.rdim + kSqueezeSeg - 1) / kSqueezeSeg) * op.other);
+            SqueezeDesc sd{a.d, re.d, o.d, op.adim, op.rdim, op.other, nullptr, 0, 0};
+            // segment geometry by the size of the step (jxl_internal.h, squeeze_seg): short segments while one wave's walk,
+            // not bandwidth, bounds the step
+            static const int64_t short_max = getenv("JXL_SQUEEZE_SHORT_MAX") ? atoll(getenv("JXL_SQUEEZE_SHORT_MAX")) : ((int64_t)8 << 20);
+            if ((int64_t)(end - begin + 1) * o.w * o.h <= short_max) {
+                sd.seg = 32;
+                sd.warm = 8;
+            }
+            if (op.rdim > squeeze_seg(sd) && !getenv("JXL_SQUEEZE_SERIAL")) {  // segmented walk: chain state per segment start
+                sd.side = alloc((size_t)((op.rdim + squeeze_seg(sd) - 1) / squeeze_seg(sd)) * op.other);
                 if (!sd.side) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze segment states)");
             }
             batch.bt.d[batch.bt.n++] = sd;
@@ -1849,6 +1858,53 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
         }
         if (batch.bt.n > 0) c->mod_ops.push_back(batch);
         ch.erase(ch.begin() + offset, ch.begin() + offset + (end - begin + 1));
+    }
+    // The leading run of small squeeze steps becomes one launch (k_squeeze_chain). A step joins the run while every channel of
+    // it is small (<= 256 lanes, <= 40 pairs along the squeezed axis) and slot i takes its averages from slot i of the step before (or
+    // from an input channel) and its residuals from an input channel: then one workgroup per slot needs no other workgroup.
+    if (!getenv("JXL_SQUEEZE_NO_CHAIN")) {
+        size_t run = 0;
+        int slots = 0;
+        while (run < c->mod_ops.size()) {
+            const ModOp& op = c->mod_ops[run];
+            if (op.kind != 4 || op.bt.n > 8) break;
+            bool ok = true;
+            for (int i = 0; i < op.bt.n && ok; i++) {
+                const SqueezeDesc& d = op.bt.d[i];
+                // (one workgroup walks a channel's rows / columns serially, ~100 cycles per pair: worth a launch boundary (~7 us)
+                // only while the axis is short. Measured on the 1080p plan: 11 steps in the chain 0.277 ms, none 0.247 ms)
+                static const int chain_max = getenv("JXL_SQUEEZE_CHAIN_MAX") ? atoi(getenv("JXL_SQUEEZE_CHAIN_MAX")) : 40;
+                ok = d.other <= 256 && d.rdim <= chain_max;
+                // averages: slot i of the previous step, or not an output of any earlier step of the run
+                for (size_t q = 0; q < run && ok; q++)
+                    for (int j = 0; j < c->mod_ops[q].bt.n && ok; j++) {
+                        const int32_t* o = c->mod_ops[q].bt.d[j].o;
+                        if (d.b == o) ok = false;
+                        if (d.a == o && !(q + 1 == run && j == i)) ok = false;
+                    }
+            }
+            if (!ok) break;
+            slots = std::max(slots, op.bt.n);
+            run++;
+        }
+        if (run >= 2) {
+            std::vector<SqueezeBatch> steps;
+            for (size_t q = 0; q < run; q++) {
+                SqueezeBatch bt = c->mod_ops[q].bt;
+                for (int i = 0; i < bt.n; i++) bt.d[i].side = nullptr;  // full serial walks: no segment states
+                steps.push_back(bt);
+            }
+            c->mod_bufs.emplace_back();
+            if (!c->mod_bufs.back().ensure(sizeof(SqueezeBatch) * steps.size())) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze chain)");
+            HIP_TRY(c, hipMemcpy(c->mod_bufs.back().p, steps.data(), sizeof(SqueezeBatch) * steps.size(), hipMemcpyHostToDevice));
+            ModOp chain{};
+            chain.kind = 5;
+            chain.chain_dev = c->mod_bufs.back().as<SqueezeBatch>();
+            chain.chain_steps = (int)run;
+            chain.chain_slots = slots;
+            c->mod_ops.erase(c->mod_ops.begin(), c->mod_ops.begin() + run);
+            c->mod_ops.insert(c->mod_ops.begin(), chain);
+        }
     }
     if (rct_type >= 0) {  // RCT branch (:255-326)
         if (rct_begin < 0 || rct_begin + 2 >= (int)ch.size()) return fail(c, JXL_ERR_INVALID_ARGUMENT, "rct channels out of range");
@@ -1889,6 +1945,7 @@ jxl_status jxl_modular_run(jxl_ctx* c) {
         case 2: launch_rct(op.v0, op.v1, op.v2, op.n, op.type, c->stream); break;
         case 3: (void)hipMemcpyAsync(op.o, op.a, 4 * (size_t)op.n, hipMemcpyDeviceToDevice, c->stream); break;
         case 4: launch_squeeze_batch(op.bt, c->stream); break;
+        case 5: launch_squeeze_chain(op.chain_dev, op.chain_steps, op.chain_slots, c->stream); break;
         }
         launches++;
     }

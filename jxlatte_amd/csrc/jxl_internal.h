@@ -191,7 +191,10 @@ struct SqueezeDesc {
     int adim, rdim;    // squeezed-axis length of a and b (widths for H, heights for V)
     int other;         // the other dimension (rows for H, columns for V)
     int32_t* side;     // [nseg][other] chain state at every segment start (segmented mode), or null: one segment
+    int seg, warm;     // pairs per segment and warm-up pairs in front of it (multiples of 8); 0: kSqueezeSeg / kSqueezeWarm
 };
+__host__ __device__ inline int squeeze_seg(const SqueezeDesc& d);
+__host__ __device__ inline int squeeze_warm(const SqueezeDesc& d);
 // The recurrence (left = previously output odd sample) is serial along the squeezed axis, but it forgets its start
 // within a few pairs (tendency() is clamped to [0, 2(avg - nextAvg)], so every step maps all inputs to a handful of
 // outputs: measured 1-2 pairs on average, 6 at most on photographic, synthetic and white-noise rows). So the axis is cut
@@ -200,15 +203,31 @@ struct SqueezeDesc {
 // kernel compares that state with the true one (the last output of segment s-1); every segment of a row / column whose
 // boundaries all match is exact by induction, and a row / column with a mismatch (constructible, not observed) is redone
 // serially from its first bad boundary. Results are bit-identical to the serial walk in every case.
-constexpr int kSqueezeSeg = 64;
-constexpr int kSqueezeWarm = 16;
+#ifndef JXL_SQUEEZE_SEG
+#define JXL_SQUEEZE_SEG 64
+#endif
+#ifndef JXL_SQUEEZE_WARM
+#define JXL_SQUEEZE_WARM 16
+#endif
+constexpr int kSqueezeSeg = JXL_SQUEEZE_SEG;
+constexpr int kSqueezeWarm = JXL_SQUEEZE_WARM;
 struct SqueezeBatch {
     int n;
     int horizontal;
     SqueezeDesc d[8];
 };
-__host__ __device__ inline int squeeze_segments(const SqueezeDesc& d) { return d.side && d.rdim > kSqueezeSeg ? (d.rdim + kSqueezeSeg - 1) / kSqueezeSeg : 1; }
+// Small steps are bound by the time ONE wave needs for its segment (~130 cycles per pair), large ones by bandwidth: the host
+// gives steps of up to 8 Mi samples 32-pair segments with an 8-pair warm-up (measured: 1080p image 0.245 -> 0.195 ms) and
+// keeps 64 + 16 beyond (8K image: 0.78 ms against 0.80 ms with 32 + 8 everywhere).
+__host__ __device__ inline int squeeze_seg(const SqueezeDesc& d) { return d.seg > 0 ? d.seg : kSqueezeSeg; }
+__host__ __device__ inline int squeeze_warm(const SqueezeDesc& d) { return d.seg > 0 ? d.warm : kSqueezeWarm; }
+__host__ __device__ inline int squeeze_segments(const SqueezeDesc& d) {
+    return d.side && d.rdim > squeeze_seg(d) ? (d.rdim + squeeze_seg(d) - 1) / squeeze_seg(d) : 1;
+}
 void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s);
+// a run of small steps in one launch: dev_steps = the steps' SqueezeBatch blocks in device memory, slot i of every step by
+// workgroup i (the caller has checked that slot i of a step depends on slot i of the step before only)
+void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slots, hipStream_t s);
 void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out, hipStream_t s);
 void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh, int w, int32_t* out, hipStream_t s);
 void launch_rct(int32_t* v0, int32_t* v1, int32_t* v2, int64_t n, int type, hipStream_t s);

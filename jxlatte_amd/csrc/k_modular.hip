@@ -135,9 +135,9 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
     const int nseg = squeeze_segments(d);
     const int s = blockIdx.z;
     if (s >= nseg) return;
-    const int yb = s * kSqueezeSeg;
-    const int ye = nseg == 1 ? rh : min(rh, yb + kSqueezeSeg);
-    const int ys = s > 0 ? yb - kSqueezeWarm : 0;
+    const int yb = s * squeeze_seg(d);
+    const int ye = nseg == 1 ? rh : min(rh, yb + squeeze_seg(d));
+    const int ys = s > 0 ? yb - squeeze_warm(d) : 0;
     const int32_t* __restrict__ avg = d.a + (int64_t)x * al;
     const int32_t* __restrict__ res = d.b + (int64_t)x * rl;
     int32_t* __restrict__ out = d.o + (int64_t)x * ol;
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(64) void k_squeeze_verify(const SqueezeBatch bt) {
     auto po = [&](int k) { return hz ? out + (int64_t)i * ow + k : out + (int64_t)k * n + i; };
     int bad = 0;
     for (int s = nseg - 1; s >= 1; s--)
-        if (d.side[(int64_t)s * n + i] != *po(2 * s * kSqueezeSeg - 1)) bad = s;
+        if (d.side[(int64_t)s * n + i] != *po(2 * s * squeeze_seg(d) - 1)) bad = s;
     if (__builtin_expect(bad == 0, 1)) return;
-    int32_t left = *po(2 * bad * kSqueezeSeg - 1);
-    for (int k = bad * kSqueezeSeg; k < rdim; k++) {
+    int32_t left = *po(2 * bad * squeeze_seg(d) - 1);
+    for (int k = bad * squeeze_seg(d); k < rdim; k++) {
         const int32_t a = at_a(k);
         const int32_t nx = k + 1 < adim ? at_a(k + 1) : a;
         const int32_t diff = wadd(at_r(k), tendency(left, a, nx));
@@ -301,9 +301,9 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
     const int nseg = squeeze_segments(d);
     const int s = blockIdx.z;
     if (s >= nseg) return;
-    const int xb = s * kSqueezeSeg;
-    const int xe = nseg == 1 ? rw : min(rw, xb + kSqueezeSeg);
-    const int xs = s > 0 ? xb - kSqueezeWarm : 0;
+    const int xb = s * squeeze_seg(d);
+    const int xe = nseg == 1 ? rw : min(rw, xb + squeeze_seg(d));
+    const int xs = s > 0 ? xb - squeeze_warm(d) : 0;
     const int32_t* __restrict__ avg = d.a;
     const int32_t* __restrict__ res = d.b;
     int32_t* __restrict__ out = d.o;
@@ -435,6 +435,79 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
     if (s == 0 && aw > rw && lane < rows) out[(int64_t)(y0 + lane) * ow + 2 * rw] = avg[(int64_t)(y0 + lane) * aw + rw];
 }
 
+// ---- the coarse levels as ONE launch ------------------------------------------------------------------------------------
+// The first inverse steps of a squeeze plan work on a few thousand samples each (the default plan of a 1080p image starts
+// at 8 x 5 and doubles one axis per step): as launches of their own they cost a launch boundary each and nothing else
+// (measured round 1: ~30 dependent launches of 5-20 us = the whole 0.22 ms of a 1080p image). In the in-place part of a plan
+// channel i of step k+1 takes the output of channel i of step k as its averages and an untouched input channel as its
+// residuals, so a workgroup can run one channel through a whole run of steps by itself: workgroup = channel slot, lanes =
+// rows (H) / columns (V), every lane walking its row / column serially from the true start (no segments, nothing to
+// verify), a workgroup barrier between steps (the planes are a few KB: they stay in the CU's L1 / the XCD's L2).
+__global__ __launch_bounds__(256) void k_squeeze_chain(const SqueezeBatch* __restrict__ steps, int n_steps) {
+    const int slot = blockIdx.x;
+    for (int k = 0; k < n_steps; k++) {
+        const SqueezeBatch& bt = steps[k];
+        if (slot < bt.n) {
+            const SqueezeDesc d = bt.d[slot];
+            const bool hz = bt.horizontal != 0;
+            const int n = d.other, adim = d.adim, rdim = d.rdim;
+            const int ow = adim + rdim;
+            for (int i = threadIdx.x; i < n; i += 256) {
+                // element j of the squeezed axis of lane i
+                const int64_t ab = hz ? (int64_t)i * adim : i, as = hz ? 1 : n;
+                const int64_t rb = hz ? (int64_t)i * rdim : i, rs = hz ? 1 : n;
+                const int64_t ob = hz ? (int64_t)i * ow : i, os = hz ? 1 : n;
+                int32_t a = rdim > 0 || adim > 0 ? d.a[ab] : 0;
+                int32_t left = a;  // the first pair uses its own average (ModularChannel.java:370, :399)
+                // chunks of 8 pairs: the averages and residuals of a chunk do not depend on the recurrence, so they are all
+                // requested before its serial chain runs, and the next chunk's before that (a dependent L2 round trip per
+                // pair made this kernel slower than the eleven launches it replaces)
+                constexpr int RV = 8;
+                int32_t rn[RV], an[RV];
+                auto fetch = [&](int j0, int32_t* r_, int32_t* a_) {
+#pragma unroll
+                    for (int q = 0; q < RV; q++) {
+                        const int j = j0 + q;
+                        r_[q] = j < rdim ? d.b[rb + (int64_t)j * rs] : 0;
+                        a_[q] = j + 1 < adim ? d.a[ab + (int64_t)(j + 1) * as] : 0;
+                    }
+                };
+                fetch(0, rn, an);
+                for (int j0 = 0; j0 < rdim; j0 += RV) {
+                    int32_t rr[RV], na[RV];
+#pragma unroll
+                    for (int q = 0; q < RV; q++) {
+                        rr[q] = rn[q];
+                        na[q] = an[q];
+                    }
+                    if (j0 + RV < rdim) fetch(j0 + RV, rn, an);
+#pragma unroll
+                    for (int q = 0; q < RV; q++) {
+                        const int j = j0 + q;
+                        if (j < rdim) {
+                            const int32_t nx = j + 1 < adim ? na[q] : a;
+                            const int32_t diff = wadd(rr[q], tendency(left, a, nx));
+                            const int32_t first = wadd(a, diff / 2);
+                            const int32_t second = wsub(first, diff);
+                            d.o[ob + (int64_t)(2 * j) * os] = first;
+                            d.o[ob + (int64_t)(2 * j + 1) * os] = second;
+                            left = second;
+                            a = nx;
+                        }
+                    }
+                }
+                if (adim > rdim) d.o[ob + (int64_t)(2 * rdim) * os] = d.a[ab + (int64_t)rdim * as];
+            }
+        }
+        __syncthreads();  // (workgroup-scope release / acquire of the global stores above: one CU, one L1)
+    }
+}
+
+void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slots, hipStream_t s) {
+    if (n_steps <= 0 || n_slots <= 0) return;
+    hipLaunchKernelGGL(k_squeeze_chain, dim3(n_slots), dim3(256), 0, s, dev_steps, n_steps);
+}
+
 void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s) {
     if (bt.n <= 0) return;
     int maxdim = 0, nseg = 1;
@@ -462,7 +535,7 @@ void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw,
     SqueezeBatch bt{};
     bt.n = 1;
     bt.horizontal = 1;
-    bt.d[0] = SqueezeDesc{avg, res, out, aw, rw, h, nullptr};
+    bt.d[0] = SqueezeDesc{avg, res, out, aw, rw, h, nullptr, 0, 0};
     launch_squeeze_batch(bt, s);
 }
 
@@ -471,7 +544,7 @@ void launch_inv_vsqueeze(const int32_t* avg, int ah, const int32_t* res, int rh,
     SqueezeBatch bt{};
     bt.n = 1;
     bt.horizontal = 0;
-    bt.d[0] = SqueezeDesc{avg, res, out, ah, rh, w, nullptr};
+    bt.d[0] = SqueezeDesc{avg, res, out, ah, rh, w, nullptr, 0, 0};
     launch_squeeze_batch(bt, s);
 }
 
