@@ -277,8 +277,8 @@ struct Raw {
 // block records the prefetch of an item will need: its groups' blocks and (lanes < NLLF) the block of its LLF coefficient
 template <int NG>
 struct Recs {
-    v4i g[NG];
-    v4i l;
+    int gx[NG], gz[NG], gw[NG];  // DevBlock words 0 (cy | cx << 16), 2 (cfl_zero), 3 (hf_mul) of the groups' blocks
+    int lx;                      // word 0 of the LLF lane's block
 };
 
 template <int NG>
@@ -288,13 +288,21 @@ __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int 
     const int per_b = 3 * (H >> 3) * (W >> 3);
 #pragma unroll
     for (int j = 0; j < NG; j++) {
-        rc.g[j] = v4i{0, 0, 0, 1};
+        rc.gx[j] = rc.gz[j] = 0;
+        rc.gw[j] = 1;
         const int b = (tid + 256 * j) >> lgGPB;
-        if (it.type >= 0 && b < it.nb) rc.g[j] = ((cv4ip)a.blocks)[it.first + b];
+        if (it.type >= 0 && b < it.nb) {
+            // three dword loads straight into the three loop-carried registers: one 16-byte load would land in a temporary
+            // and have to be COPIED into them, i.e. waited for right here (a full L2 round trip per item, measured)
+            const auto* w = (const __attribute__((address_space(4))) int*)a.blocks + 4 * (it.first + b);
+            rc.gx[j] = w[0];
+            rc.gz[j] = w[2];
+            rc.gw[j] = w[3];
+        }
     }
-    rc.l = v4i{0, 0, 0, 1};
+    rc.lx = 0;
     const int bl = tid / per_b;
-    if (it.type >= 0 && bl < it.nb) rc.l = ((cv4ip)a.blocks)[it.first + bl];
+    if (it.type >= 0 && bl < it.nb) rc.lx = ((const __attribute__((address_space(4))) int*)a.blocks)[4 * (it.first + bl)];
 }
 
 // issue every load of item `it` this lane will need at dequantisation time (type-generic: run-time geometry)
@@ -321,10 +329,9 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
         raw.kx[j] = raw.kb[j] = 0.0f;
         raw.hfm[j] = 1.0f;
         if (it.type >= 0 && b < it.nb) {
-            const v4i rec = rc.g[j];  // DevBlock
-            const int cy = (int)((uint32_t)rec.x & 0xffffu), cx = (int)((uint32_t)rec.x >> 16);
-            const uint32_t cfl_zero = (uint32_t)rec.z;
-            raw.hfm[j] = (float)rec.w;
+            const int cy = (int)((uint32_t)rc.gx[j] & 0xffffu), cx = (int)((uint32_t)rc.gx[j] >> 16);  // DevBlock
+            const uint32_t cfl_zero = (uint32_t)rc.gz[j];
+            raw.hfm[j] = (float)rc.gw[j];
             const int py = cy * 8 + n, px = cx * 8 + x4;
             const int64_t off = (int64_t)py * f.width + px;
 #pragma unroll
@@ -347,7 +354,7 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     if (it.type >= 0 && bl < it.nb) {
         const int rr = tid - bl * per_b, c = rr / (dsh * dsw), k = rr - c * (dsh * dsw);
         const int ky = k / dsw, kx = k - ky * dsw;
-        const int cy = (int)((uint32_t)rc.l.x & 0xffffu), cx = (int)((uint32_t)rc.l.x >> 16);
+        const int cy = (int)((uint32_t)rc.lx & 0xffffu), cx = (int)((uint32_t)rc.lx >> 16);
         raw.llf = f.llf[c][(int64_t)(cy + ky) * f.bw + cx + kx];
     }
 }
@@ -428,7 +435,9 @@ struct Body {
     }
 
     // ---- B + C. column pass (in place), row pass -> frame planes
-    static __device__ __forceinline__ void passes(const Wg3Args& a, const Item& it, int tid, float* __restrict__ img, int it_no) {
+    template <typename PreStore>
+    static __device__ __forceinline__ void passes(const Wg3Args& a, const Item& it, int tid, float* __restrict__ img, int it_no,
+                                                  PreStore pre_store) {
         (void)it_no;
         const DevFrame& f = a.f;
         const cfloatp lut_h = (cfloatp)(f.lut + lut_off(clog2(H)));
@@ -468,6 +477,7 @@ struct Body {
             const float* r1 = img + (1 * C::NB + rb) * C::IMG + ry * C::LD;
             const float* r2 = img + (2 * C::NB + rb) * C::IMG + ry * C::LD;
             idct1d3<KC, W>(acc, lut_w + kc_row * (KC / 2), r0, r1, r2, 1);
+            pre_store();
             STAMP3(7);
             if (rb < it.nb) {
                 float* o3[3] = {a.o0, a.o1, a.o2};
@@ -499,7 +509,7 @@ __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int
         case 18: Body<64, 64, 18>::dequant(a, it, tid, raw, img, qtab); break;
         case 19: Body<64, 32, 19>::dequant(a, it, tid, raw, img, qtab); break;
         case 20: Body<32, 64, 20>::dequant(a, it, tid, raw, img, qtab); break;
-        default: break;
+        default: __builtin_unreachable();  // item_of hands out the types of this class only
         }
     } else {
         switch (it.type) {
@@ -512,31 +522,31 @@ __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int
         case 9: Body<8, 32, 9>::dequant(a, it, tid, raw, img, qtab); break;
         case 10: Body<32, 16, 10>::dequant(a, it, tid, raw, img, qtab); break;
         case 11: Body<16, 32, 11>::dequant(a, it, tid, raw, img, qtab); break;
-        default: break;
+        default: __builtin_unreachable();  // item_of hands out the types of this class only
         }
     }
 }
-template <bool BIG>
-__device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int tid, float* img, int it_no) {
+template <bool BIG, typename PreStore>
+__device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int tid, float* img, int it_no, PreStore pre_store) {
     if constexpr (BIG) {
         switch (it.type) {
-        case 18: Body<64, 64, 18>::passes(a, it, tid, img, it_no); break;
-        case 19: Body<64, 32, 19>::passes(a, it, tid, img, it_no); break;
-        case 20: Body<32, 64, 20>::passes(a, it, tid, img, it_no); break;
-        default: break;
+        case 18: Body<64, 64, 18>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 19: Body<64, 32, 19>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 20: Body<32, 64, 20>::passes(a, it, tid, img, it_no, pre_store); break;
+        default: __builtin_unreachable();  // item_of hands out the types of this class only
         }
     } else {
         switch (it.type) {
-        case 0: Body<8, 8, 0>::passes(a, it, tid, img, it_no); break;
-        case 4: Body<16, 16, 4>::passes(a, it, tid, img, it_no); break;
-        case 5: Body<32, 32, 5>::passes(a, it, tid, img, it_no); break;
-        case 6: Body<16, 8, 6>::passes(a, it, tid, img, it_no); break;
-        case 7: Body<8, 16, 7>::passes(a, it, tid, img, it_no); break;
-        case 8: Body<32, 8, 8>::passes(a, it, tid, img, it_no); break;
-        case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no); break;
-        case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no); break;
-        case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no); break;
-        default: break;
+        case 0: Body<8, 8, 0>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 4: Body<16, 16, 4>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 5: Body<32, 32, 5>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 6: Body<16, 8, 6>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 7: Body<8, 16, 7>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 8: Body<32, 8, 8>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no, pre_store); break;
+        default: __builtin_unreachable();  // item_of hands out the types of this class only
         }
     }
 }
@@ -551,7 +561,7 @@ __device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int 
 // Two instantiations by register / LDS class: BIG = the 64-point family (4096 positions per item: 50 KB of LDS, 4 groups
 // per lane), !BIG = everything up to 32 points (2048 positions: <= 34 KB).
 #ifndef WG3_SMALL_OCC
-#define WG3_SMALL_OCC 3
+#define WG3_SMALL_OCC 4
 #endif
 template <bool BIG>
 __global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const Wg3Args a) {
@@ -574,6 +584,23 @@ __global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const
     prefetch<NG>(a, cur, tid0, rc, raw);
     Item nxt = item_of<P>(a, gi + G);
     load_recs<NG>(a, nxt, tid0, rc);
+    // "every load issued so far has landed": an empty asm that reads the destination registers makes the compiler place the
+    // wait HERE. Used (i) once before the loop -- the first item needs its data anyway, and the loop header then has no load
+    // in flight on either incoming edge, so no conservative vmcnt wait is generated inside the loop -- and (ii) in every
+    // item right before its stores are issued: the prefetch and the records have had both passes to arrive, so the wait is
+    // free there, whereas any wait for them AFTER the stores (vmcnt counts loads and stores in one in-order queue) would last
+    // until the stores have drained.
+    auto loads_landed = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            asm volatile("" ::"v"(raw.q[j][0]), "v"(raw.q[j][1]), "v"(raw.q[j][2]), "v"(raw.kx[j]), "v"(raw.kb[j]), "v"(rc.gx[j]), "v"(rc.gz[j]),
+                         "v"(rc.gw[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < (NG == 2 ? 1 : NG); j++) asm volatile("" ::"v"(raw.w[j][0]), "v"(raw.w[j][1]), "v"(raw.w[j][2]));
+        asm volatile("" ::"v"(raw.llf), "v"(rc.lx));
+    };
+    loads_landed();
     lds_barrier();  // qtab
     int it_no = 0;
 #pragma unroll 1
@@ -594,7 +621,7 @@ __global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const
         const Item nn = item_of<P>(a, gi + G);
         load_recs<NG>(a, nn, tid, rc);
         STAMP3(3);
-        do_passes<BIG>(a, cur, tid, img, it_no);
+        do_passes<BIG>(a, cur, tid, img, it_no, loads_landed);
         if (nxt.type < 0) break;
         cur = nxt;
         nxt = nn;

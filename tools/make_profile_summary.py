@@ -68,14 +68,20 @@ for k in sorted(dur, key=lambda k: -dur[k]):
         k, dur[k], fetch.get(k, {}).get("FETCH_SIZE", 0), write.get(k, {}).get("WRITE_SIZE", 0), s.get("SQ_WAVES", 0), s.get("SQ_INSTS_VALU", 0),
         s.get("SQ_ACTIVE_INST_VALU", 0), s.get("SQ_WAVE_CYCLES", 0), s.get("SQ_WAIT_ANY", 0), l.get("SQ_INSTS_SALU", 0),
         l.get("SQ_LDS_BANK_CONFLICT", 0), l.get("SQ_LDS_IDX_ACTIVE", 0)))
+L += ["", "IDCT stage kernels: SQ_WAIT_ANY share of the wave cycles (waves parked in s_waitcnt / barriers):", ""]
+for k in sorted(dur, key=lambda k: -dur[k]):
+    if k.startswith(("k_idct", "k_llf")) and k in sq:
+        L.append("* `%s`: %.0f %% (%.1f us per launch)" % (k, 100 * sq[k].get("SQ_WAIT_ANY", 0) / max(sq[k].get("SQ_WAVE_CYCLES", 1), 1), dur[k]))
 rk = [k for k in dur if k.startswith("k_restore_fused")][0]
 fk, wk = fetch[rk]["FETCH_SIZE"], write[rk]["WRITE_SIZE"]
 traffic = {"kernel": rk, "fetch_KiB": fk, "write_KiB": wk, "launch_us_profiled": dur[rk], "fetch_bytes_raw": fk * 1024, "write_bytes": wk * 1024,
            "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM): FETCH_SIZE doubled "
                      "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE as read; per launch, 4K frame, Gab+EPFx2+XYB"}
-json.dump(traffic, open(os.path.join(out_dir, "%s_traffic.json" % tag), "w"), indent=1)
 s = sq[rk]
+traffic["valu_wave_insts_per_launch"] = s["SQ_INSTS_VALU"]
+traffic["wait_any_share_of_wave_cycles"] = s.get("SQ_WAIT_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1)
+json.dump(traffic, open(os.path.join(out_dir, "%s_traffic.json" % tag), "w"), indent=1)
 lds_s = lds.get(rk, {})
 ISSUE_CYCLES = 2.6  # cycles one wave64 f32 VALU instruction occupies its SIMD with 8 waves per SIMD: tools/ubench/pk_rate.hip
 valu_us = s["SQ_INSTS_VALU"] * ISSUE_CYCLES / 1024 / 2.4e3
