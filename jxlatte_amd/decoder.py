@@ -295,6 +295,22 @@ def render_splines(buffers, splines, base_corr_x, base_corr_b, width, height):
 
 
 # ---- backends -------------------------------------------------------------------------------------------------
+def lf_from_lf_frame(lf_buffer, lfg_y, lfg_x, cells_h, cells_w, jpeg_up_y, jpeg_up_x, bits_per_sample):
+    """LFCoefficients.java:44-57 (USE_LF_FRAME): the dequantised LF of LF group (lfg_y, lfg_x) is a copy out of the planes a
+    preceding LF frame left in lfBuffer[] -- rows pY .. pY + size, columns from pX, with pY = lfg_y << 8, pX = lfg_x << 8 for
+    every channel (the reference does not shift the origin of a subsampled channel; kept) -- after ImageBuffer.castToFloat
+    (integer planes: v * (1f / maxValue)). Returns three float32 planes in X, Y, B order."""
+    py, px = lfg_y << 8, lfg_x << 8
+    out = []
+    for c in range(3):
+        b = lf_buffer[c]
+        if b.dtype != np.float32:
+            b = (b.astype(np.float32) * (F(1) / F((1 << bits_per_sample) - 1))).astype(np.float32)
+        h, w = cells_h >> jpeg_up_y[c], cells_w >> jpeg_up_x[c]
+        out.append(np.ascontiguousarray(b[py:py + h, px:px + w], np.float32))
+    return out
+
+
 class DeviceBackend:
     """the product backend: HIP kernels through the C-ABI (jxlatte_amd._lib / host). No CPU fallback."""
 
@@ -618,6 +634,10 @@ class JXLDecoder:
             g.update(lfg_y=i // fr.lf_group_cols, lfg_x=i % fr.lf_group_cols, lf=None,
                      scaled_dequant=list(fr.scaled_dequant), x_factor_lf=fr.x_factor_lf, b_factor_lf=fr.b_factor_lf,
                      adaptive_smoothing=adaptive)
+            if fr.flags & FLAG_USE_LF_FRAME:
+                g["lf"] = lf_from_lf_frame(self.lfBuffer[fr.lf_level], i // fr.lf_group_cols, i % fr.lf_group_cols, g["cells_h"],
+                                           g["cells_w"], list(fr.jpeg_up_y), list(fr.jpeg_up_x), info.bits_per_sample)
+                g["lf_quant"] = None
             g["block_yx"] = np.ascontiguousarray(g["block_yx"], np.int32)
             sel = g["dct_select"][g["block_yx"][:, 0], g["block_yx"][:, 1]]
             hist += np.bincount(sel, minlength=27)[:27]
@@ -783,8 +803,8 @@ class JXLDecoder:
             self.frames_decoded += 1
             self.stats.append(dict(encoding="vardct" if fr.encoding == VARDCT else "modular", width=fr.width, height=fr.height,
                                    groups=fr.num_groups, passes=fr.num_passes))
-            if fr.flags & FLAG_USE_LF_FRAME or fr.lf_level > 0:
-                raise UnsupportedOperationException("LF frames")
+            if fr.flags & FLAG_USE_LF_FRAME and self.lfBuffer[fr.lf_level] is None:
+                raise InvalidBitstreamException("LF Level too large")  # JXLCodestreamDecoder.java:613-614
             colors = self._colors(fr)
             simple = fr.upsampling == 1 and not fr.num_patches and not fr.has_splines and not fr.has_noise and \
                 not (fr.save_before_ct and not fr.is_last)
@@ -804,8 +824,15 @@ class JXLDecoder:
                 for c in range(3):
                     buffers[c] = planes[c]
             self._modular_buffers(fr, buffers, colors)
-            if fr.encoding == MODULAR and (fr.gab or fr.epf_iters > 0) and colors == 3 and buffers[0].dtype == np.float32:
-                planes = np.stack(buffers[:3])
+            if fr.encoding == MODULAR and (fr.gab or fr.epf_iters > 0):
+                # Frame.performGabConvolution casts integer colour planes to float first (Frame.java:519:
+                # ImageBuffer.castToFloat = v * (1f / maxValue)); one-colour frames keep one plane (the backends feed the
+                # three-channel kernels three copies: Frame.java:642,661 read channel 0 in all three rounds)
+                for c in range(colors):
+                    if buffers[c].dtype != np.float32:
+                        maxv = (1 << info.bits_per_sample) - 1
+                        buffers[c] = be.modular_to_float(np.ascontiguousarray(buffers[c], np.int32), None, float(F(1) / F(maxv)))
+                planes = np.stack(buffers[:colors])
                 if fr.gab:
                     planes = be.gab(planes, list(fr.gab1), list(fr.gab2))
                 if fr.epf_iters > 0:
@@ -813,8 +840,10 @@ class JXLDecoder:
                     planes = be.epf(planes, fr.epf_iters, None, float(sigma),
                                     dict(channel_scale=list(fr.epf_channel_scale), pass0=fr.epf_pass0_sigma,
                                          pass2=fr.epf_pass2_sigma, border_sad_mul=fr.epf_border_sad_mul))
-                for c in range(3):
+                for c in range(colors):
                     buffers[c] = np.ascontiguousarray(planes[c])
+            if fr.lf_level > 0:  # JXLCodestreamDecoder.java:616-617: the frame's buffers as they stand after decodeFrame
+                self.lfBuffer[fr.lf_level - 1] = [np.array(b, copy=True) for b in buffers]
             # crop to the frame bounds: everything after the restoration filters works on header.bounds
             buffers = [np.ascontiguousarray(b[:fr.height, :fr.width]) for b in buffers]
             if fr.type == LF_FRAME:

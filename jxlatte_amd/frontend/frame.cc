@@ -278,7 +278,13 @@ void Frame::read_lf_group(BitReader& br, int idx, std::vector<int>& replaced_idx
         bool subsampled = false;
         for (int i = 0; i < 3; i++) subsampled |= fh.jpeg_up_y[i] != 0 || fh.jpeg_up_x[i] != 0;
         if (adaptive && subsampled) throw BitstreamError("Adaptive Smoothing is incompatible with subsampling");
-        if (fh.flags & kUseLFFrame) throw UnsupportedError("frames that take their LF from an LF frame (USE_LF_FRAME)");
+        if (fh.flags & kUseLFFrame) {
+            // LFCoefficients.java:44-57: the LF planes are copied from the LF frame's buffer by the caller (the host layer
+            // holds lfBuffer[]); nothing is read here and lfIndex keeps its zero initialisation (:24, the early return)
+            g.has_lf_quant = false;
+            g.extra_precision = 0;
+            g.lf_index.assign((size_t)g.cells_h * g.cells_w, 0);
+        } else {
         g.extra_precision = (int)br.bits(2);
         std::vector<Channel> info(3);
         for (int i = 0; i < 3; i++)
@@ -305,6 +311,7 @@ void Frame::read_lf_group(BitReader& br, int idx, std::vector<int>& replaced_idx
                 li = li * ((int)hfctx.lf_thresholds[1].size() + 1) + index[1];
                 g.lf_index[(size_t)y * g.cells_w + x] = li;
             }
+        }
     }
     // modular channels of the frame-level stream carried by this LF group (Frame.decodeLFGroups :262-300)
     {

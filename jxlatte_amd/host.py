@@ -89,8 +89,19 @@ def performColorTransformsYCbCr(ctx, buffer):
     return out
 
 
+def _one_colour(buffer):
+    """A frame with ONE colour channel (Frame.getColorChannelCount, Frame.java:874-877: grey, not XYB, Modular). The reference's
+    EPF distance still runs its channel loop three times but reads channel 0 every time (`i = colors == 1 ? 0 : c`,
+    Frame.java:642,661): three copies of the plane through the three-channel kernels are that sum, term for term."""
+    a = np.ascontiguousarray(buffer, np.float32)
+    return a.ndim == 3 and a.shape[0] == 1
+
+
 def performGabConvolution(ctx, buffer, gab1Weights, gab2Weights):
     """Frame.performGabConvolution (Frame.java:505-542)"""
+    if _one_colour(buffer):  # channel 0 with ITS weights; the copies keep the kernels' three-plane interface
+        a = np.ascontiguousarray(buffer, np.float32)
+        return performGabConvolution(ctx, np.repeat(a, 3, axis=0), [gab1Weights[0]] * 3, [gab2Weights[0]] * 3)[:1]
     buf = _planes(buffer, np.float32)
     out = np.empty_like(buf)
     ctx.call("jxl_stage_gab", _p3(buf, C.c_float), _p3(out, C.c_float), buf.shape[1], buf.shape[2],
@@ -113,6 +124,10 @@ def performEdgePreservingFilter(ctx, buffer, epfIterations, inverseSigma=None, i
                                 epfChannelScale=(40.0, 5.0, 3.5), epfPass0SigmaScale=0.9, epfPass2SigmaScale=6.5,
                                 epfBorderSadMul=2.0 / 3.0):
     """Frame.performEdgePreservingFilter iteration loop (Frame.java:583-635)"""
+    if _one_colour(buffer):
+        a = np.ascontiguousarray(buffer, np.float32)
+        return performEdgePreservingFilter(ctx, np.repeat(a, 3, axis=0), epfIterations, inverseSigma, invModularSigma, epfChannelScale,
+                                           epfPass0SigmaScale, epfPass2SigmaScale, epfBorderSadMul)[:1]
     buf = _planes(buffer, np.float32)
     out = np.empty_like(buf)
     sig = None

@@ -52,9 +52,15 @@ class OracleBackend:
         return orc.vardct_frame(frame, threads=self.threads)
 
     def gab(self, planes, w1, w2):
+        planes = np.ascontiguousarray(planes, np.float32)
+        if planes.shape[0] == 1:  # one colour channel: orc.gab1 / orc.epf1 (Frame.java:642,661: channel 0 in all three rounds)
+            return orc.gab1(planes[0], w1[0], w2[0])[None]
         return orc.gab(planes, w1, w2)
 
     def epf(self, planes, iters, inv_sigma, sigma_modular, rf):
+        planes = np.ascontiguousarray(planes, np.float32)
+        if planes.shape[0] == 1:
+            return orc.epf1(planes[0], iters, inv_sigma, sigma_modular, rf["channel_scale"], rf["pass0"], rf["pass2"], rf["border_sad_mul"])[None]
         return orc.epf(planes, iters, inv_sigma, sigma_modular, rf["channel_scale"], rf["pass0"], rf["pass2"], rf["border_sad_mul"])
 
     def xyb(self, planes, matrix, opsin_bias, cbrt_bias, intensity_target):

@@ -142,6 +142,20 @@ def gab(planes, w1, w2):
     return out
 
 
+def gab1(plane, w1, w2):
+    """performGabConvolution of a one-colour frame (colors == 1: the channel loop runs once, Frame.java:518)"""
+    p = np.ascontiguousarray(plane, np.float32)
+    return gab(np.stack([p, p, p]), [w1] * 3, [w2] * 3)[0]
+
+
+def epf1(plane, iterations, inv_sigma, inv_sigma_modular, channel_scale, pass0, pass2, border_sad_mul):
+    """performEdgePreservingFilter of a one-colour frame: epfDistance1/2 still add three rounds, each reading buffer[0]
+    (`int i = colors == 1 ? 0 : c`, Frame.java:642,661) with that round's channel scale -- which is what the three-plane
+    restatement computes when all three planes ARE channel 0; sumChannels / outputBuffers have one entry (Frame.java:600,625)."""
+    p = np.ascontiguousarray(plane, np.float32)
+    return epf(np.stack([p, p, p]), iterations, inv_sigma, inv_sigma_modular, channel_scale, pass0, pass2, border_sad_mul)[0]
+
+
 def epf_sigma(hf_mul, sharpness, global_scale_f, sharp_lut):
     hf_mul = np.ascontiguousarray(hf_mul, np.int32)
     sharpness = np.ascontiguousarray(sharpness, np.int32)

@@ -328,3 +328,21 @@ def test_device_decode_matches_oracle_decode_large(device_backend, oracle_backen
     assert (got.getWidth(), got.getHeight()) == ((3264, 2448) if name == "ants" else (3840, 2160))
     for c, (a, b) in enumerate(zip(got.buffer, exp.buffer)):
         assert_bits_equal(a, b, "%s channel %d" % (name, c))
+
+
+def test_lf_from_lf_frame_region_and_cast():
+    """USE_LF_FRAME (LFCoefficients.java:44-57): an LF group's dequantised LF is a window of the planes the LF frame left
+    behind, origin (lfg << 8) for every channel, integer planes cast as ImageBuffer.castToFloat does. No sample bitstream
+    uses LF frames and no encoder exists here: this pins the host-side assembly only."""
+    from jxlatte_amd.decoder import lf_from_lf_frame
+    rng = np.random.default_rng(2)
+    planes = [rng.standard_normal((300, 520)).astype(np.float32) for _ in range(3)]
+    got = lf_from_lf_frame(planes, 1, 1, 44, 200, [0, 0, 0], [0, 0, 0], 8)
+    for c in range(3):
+        assert got[c].dtype == np.float32 and np.array_equal(got[c], planes[c][256:300, 256:456])
+    sub = lf_from_lf_frame(planes, 0, 1, 40, 64, [1, 0, 1], [1, 0, 0], 8)   # 4:2:0-like shifts: smaller windows, same origin
+    assert sub[0].shape == (20, 32) and sub[1].shape == (40, 64) and sub[2].shape == (20, 64)
+    assert np.array_equal(sub[0], planes[0][0:20, 256:288])
+    ints = [rng.integers(0, 1024, (260, 260)).astype(np.int32) for _ in range(3)]
+    gi = lf_from_lf_frame(ints, 0, 0, 8, 8, [0, 0, 0], [0, 0, 0], 10)
+    assert np.array_equal(gi[1], (ints[1][:8, :8].astype(np.float32) * (np.float32(1) / np.float32(1023))).astype(np.float32))

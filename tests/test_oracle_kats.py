@@ -442,3 +442,72 @@ def test_tendency_min_max_form(orc):
     diff1 = r[:, 1] + t1
     first1 = a[:, 1] + tdiv(diff1, 2)
     assert np.array_equal(out[:, 2], first1) and np.array_equal(out[:, 3], first1 - diff1)
+
+
+def test_one_colour_epf_and_gab_python_restatement(orc):
+    """colors == 1 (grey, non-XYB Modular frame with restoration filters): plain-Python restatement of Frame.java:583-679 for
+    one colour channel -- the distance still has three rounds, all on channel 0, each with its own channel scale (`i = colors
+    == 1 ? 0 : c`) -- against the oracle's epf1 / gab1 on a small plane, every EPF iteration count"""
+    F = np.float32
+    rng = np.random.default_rng(12)
+    h, w = 11, 13
+    p = (rng.standard_normal((h, w)) * 0.05).astype(F)
+    scale, pass0, pass2, bsm, inv_sigma = [F(40.0), F(5.0), F(3.5)], F(0.9), F(6.5), F(2.0) / F(3.0), F(0.8)
+    step = F(1.65) * F(4) * (F(1) - F(np.sqrt(0.5)))
+
+    def mir(c, n):
+        while c < 0 or c >= n:
+            c = -c - 1 if c < 0 else 2 * n - 1 - c
+        return c
+    cross = [(0, 0), (0, -1), (0, 1), (-1, 0), (1, 0)]
+    dcross = cross + [(-1, 1), (1, 1), (1, -1), (-1, -1), (0, -2), (0, 2), (2, 0), (-2, 0)]
+
+    def run(src, iters):
+        cur = src.copy()
+        for i in range(3):
+            if i == 0 and iters < 3:
+                continue
+            if i == 2 and iters < 2:
+                break
+            ss = step * (pass0 if i == 0 else pass2 if i == 2 else F(1))
+            taps = dcross if i == 0 else cross
+            out = np.empty_like(cur)
+            for y in range(h):
+                for x in range(w):
+                    sw, sc = F(0), F(0)
+                    for (ty, tx) in taps:
+                        d = F(0)
+                        for c in range(3):
+                            if i == 2:
+                                d = F(d + F(abs(F(cur[y, x] - cur[mir(y + ty, h), mir(x + tx, w)]))) * scale[c])
+                            else:
+                                for (qy, qx) in cross:
+                                    a = cur[mir(y + qy, h), mir(x + qx, w)]
+                                    b = cur[mir(y + ty + qy, h), mir(x + tx + qx, w)]
+                                    d = F(d + F(abs(F(a - b))) * scale[c])
+                        if (y & 7) in (0, 7) or (x & 7) in (0, 7):
+                            d = F(d * bsm)
+                        v = F(F(1) - F(F(d * ss) * inv_sigma))
+                        wgt = v if v > 0 else F(0)
+                        sw = F(sw + wgt)
+                        sc = F(sc + F(cur[mir(y + ty, h), mir(x + tx, w)] * wgt))
+                    out[y, x] = F(sc / sw)
+            cur = out
+        return cur
+    for iters in (1, 2, 3):
+        got = orc.epf1(p, iters, None, float(inv_sigma), [float(s) for s in scale], float(pass0), float(pass2), float(bsm))
+        exp = run(p, iters)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), iters
+    # Gaborish of one channel: its own weights, clamped edges (Frame.java:505-542)
+    w1, w2 = F(0.115169525), F(0.061248592)
+    mult = F(1) / (F(1) + F(4) * (w1 + w2))
+    exp = np.empty_like(p)
+    for y in range(h):
+        n, s_ = max(y - 1, 0), min(y + 1, h - 1)
+        for x in range(w):
+            we, ea = max(x - 1, 0), min(x + 1, w - 1)
+            adj = F(F(F(p[y, we] + p[y, ea]) + p[n, x]) + p[s_, x])
+            diag = F(F(F(p[n, we] + p[n, ea]) + p[s_, we]) + p[s_, ea])
+            exp[y, x] = F(F(mult * p[y, x] + F(w1 * mult) * adj) + F(w2 * mult) * diag)
+    got = orc.gab1(p, float(w1), float(w2))
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))

@@ -206,3 +206,18 @@ def test_u16_pq_output_path(ctx, orc):
     assert got.dtype == np.uint16
     d = np.abs(got.astype(np.int64) - exp.astype(np.int64))
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("iters", [1, 2, 3])
+def test_one_colour_gab_and_epf(ctx, orc, iters):
+    """frames with one colour channel (grey Modular with restoration filters, Frame.java:638-669 `i = colors == 1 ? 0 : c`):
+    the device path feeds the three-channel kernels three copies of channel 0; against the oracle's one-colour form"""
+    rng = np.random.default_rng(60 + iters)
+    p = (rng.standard_normal((1, 45, 83)) * 0.08).astype(F)
+    g = host.performGabConvolution(ctx, p, [0.115169525, 0.3, 0.4], [0.061248592, 0.2, 0.1])
+    assert g.shape == p.shape
+    assert_bits_equal(g[0], orc.gab1(p[0], 0.115169525, 0.061248592), "gab one colour")
+    args = ((40.0, 5.0, 3.5), 0.9, 6.5, 2.0 / 3.0)
+    e = host.performEdgePreservingFilter(ctx, g, iters, None, 0.7, *args)
+    assert e.shape == p.shape
+    assert_bits_equal(e[0], orc.epf1(g[0], iters, None, 0.7, *args), "epf one colour it%d" % iters)
