@@ -208,6 +208,31 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n);
 jxl_status jxl_vardct_finish_frame(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
 /* copy the last run's result planes (device) to host without re-running */
 jxl_status jxl_vardct_read_output(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
+/* ---- the frame's colour planes kept on the device between the stages that follow decodeFrame --------------------------
+ * JXLCodestreamDecoder.decode runs, on the frame's own buffers and in this order (JXLCodestreamDecoder.java:628-637):
+ * Frame.upsample, Frame.initializeNoise, computePatches, Frame.renderSplines, Frame.synthesizeNoise,
+ * performColorTransforms. The jxl_stage_* entries take and return host planes; these entries run the same kernels on a set
+ * of three float planes that STAYS in device memory, so a frame with upsampling / noise costs one transfer in (its
+ * coefficients) and one out (its pixels). Patches and splines stay host code (as in the reference): jxl_planes_download /
+ * jxl_planes_upload bracket them, only for frames that have them. */
+/* adopt the top-left height x width window (Frame bounds; the restoration filters worked on the padded size) of the last
+ * jxl_vardct_run's result as the resident planes. The run must have produced float planes (no transfer / integer output;
+ * XYB stage off if the later stages need XYB samples). */
+jxl_status jxl_planes_from_frame(jxl_ctx* ctx, int32_t height, int32_t width);
+/* Frame.performUpsampling (Frame.java:217-260) of the three planes, k = 2, 4, 8; weights as for jxl_stage_upsample */
+jxl_status jxl_planes_upsample(jxl_ctx* ctx, int32_t k, const float* weights);
+/* Frame.initializeNoise (Frame.java:748-788) + Frame.synthesizeNoise (:790-831) on the resident planes */
+jxl_status jxl_planes_noise(jxl_ctx* ctx, int32_t group_dim, uint64_t seed0, const float lut[8], float base_corr_x, float base_corr_b);
+/* OpsinInverseMatrix.invertXYB / the YCbCr branch of performColorTransforms on the resident planes */
+jxl_status jxl_planes_xyb(jxl_ctx* ctx, const float matrix[9], const float opsin_bias[3], const float cbrt_opsin_bias[3],
+                          float intensity_target);
+jxl_status jxl_planes_ycbcr(jxl_ctx* ctx);
+/* current size of the resident planes */
+jxl_status jxl_planes_shape(const jxl_ctx* ctx, int32_t* height, int32_t* width);
+/* the host hook (patches, splines, saveBeforeCT references) and the way out: dense height x width float planes */
+jxl_status jxl_planes_download(jxl_ctx* ctx, float* const out[3]);
+jxl_status jxl_planes_upload(jxl_ctx* ctx, const float* const in[3], int32_t height, int32_t width);
+
 /* device-to-device copy of the result into caller-owned device memory (e.g. an RCCL send
  * buffer): dst = 3 planes back to back, width*height elements each. Async on the ctx stream. */
 jxl_status jxl_vardct_copy_output_device(jxl_ctx* ctx, void* dst_device);

@@ -73,6 +73,14 @@ SIGNATURES = {
     "jxl_vardct_finish_frame": (i32, [vp, pv3, i64]),
     "jxl_vardct_read_output": (i32, [vp, pv3, i64]),
     "jxl_vardct_copy_output_device": (i32, [vp, vp]),
+    "jxl_planes_from_frame": (i32, [vp, i32, i32]),
+    "jxl_planes_upsample": (i32, [vp, i32, pf]),
+    "jxl_planes_noise": (i32, [vp, i32, C.c_uint64, pf, f32, f32]),
+    "jxl_planes_xyb": (i32, [vp, pf, pf, pf, f32]),
+    "jxl_planes_ycbcr": (i32, [vp]),
+    "jxl_planes_shape": (i32, [vp, pi, pi]),
+    "jxl_planes_download": (i32, [vp, pf3]),
+    "jxl_planes_upload": (i32, [vp, pf3, i32, i32]),
     "jxl_vardct_out_elem_size": (i32, [vp]),
     "jxl_vardct_last_launch_count": (i32, [vp]),
     "jxl_vardct_last_stage_ms": (i32, [vp, i32, pf]),

@@ -86,6 +86,9 @@ struct jxl_ctx {
     std::vector<LfJob> lf_jobs;  // integer LF images to dequantise + smooth on the device (row f1)
     DevBuf lfq_tmp[3];
     DevBuf pq_tab;  // PQ segment table (jxl_fastpow.h), uploaded at context creation
+    // resident colour planes between decodeFrame and the colour transform (jxl_planes_*): dense [rp_h][rp_w] floats
+    DevBuf rp[3], rp_tmp[3], rp_noise[3];
+    int rp_h = 0, rp_w = 0;
     // binned work
     // one merged launch: the segments (types) of one register class; channel >= 0: chroma-subsampled frame, one channel per launch
     struct TypeLaunch { int cls, channel; std::vector<IdctSegment> segs; };
@@ -541,6 +544,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     }
     for (int i = 0; i < 3; i++) c->hfm_sub[i].release();
     c->pq_tab.release();
+    for (int i = 0; i < 3; i++) { c->rp[i].release(); c->rp_tmp[i].release(); c->rp_noise[i].release(); }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++)
@@ -1309,6 +1313,115 @@ jxl_status jxl_vardct_copy_output_device(jxl_ctx* c, void* dst_device) {
     }
     for (int i = 0; i < 3; i++)
         HIP_TRY(c, hipMemcpyAsync((char*)dst_device + i * bytes, c->result[i], bytes, hipMemcpyDeviceToDevice, c->stream));
+    return JXL_OK;
+}
+
+// ---- resident colour planes (the stages of JXLCodestreamDecoder.java:628-637 chained on the device) -----------------------
+jxl_status jxl_planes_from_frame(jxl_ctx* c, int32_t height, int32_t width) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->result[0]) return fail(c, JXL_ERR_STATE, "nothing has been run");
+    if (c->result_elem != 4 || c->result_interleaved || ((c->p.stages & JXL_STAGE_OUT) && (c->p.transfer != JXL_TRANSFER_NONE || c->p.out_format != JXL_OUT_F32)))
+        return fail(c, JXL_ERR_STATE, "the frame's result is not a set of float planes");
+    if (height <= 0 || width <= 0 || height > c->H || width > c->W) return fail(c, JXL_ERR_INVALID_ARGUMENT, "planes: window outside the frame");
+    for (int i = 0; i < 3; i++) {
+        if (!c->rp[i].ensure(sizeof(float) * (size_t)height * width)) return fail(c, JXL_ERR_OOM, "device allocation failed (resident planes)");
+        HIP_TRY(c, hipMemcpy2DAsync(c->rp[i].p, sizeof(float) * (size_t)width, c->result[i], sizeof(float) * (size_t)c->W,
+                                    sizeof(float) * (size_t)width, (size_t)height, hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->rp_h = height;
+    c->rp_w = width;
+    return JXL_OK;
+}
+
+jxl_status jxl_planes_shape(const jxl_ctx* c, int32_t* height, int32_t* width) {
+    if (!c || !height || !width) return JXL_ERR_INVALID_ARGUMENT;
+    *height = c->rp_h;
+    *width = c->rp_w;
+    return JXL_OK;
+}
+
+jxl_status jxl_planes_upsample(jxl_ctx* c, int32_t k, const float* weights) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (c->rp_h <= 0) return fail(c, JXL_ERR_STATE, "no resident planes");
+    if (!weights || (k != 2 && k != 4 && k != 8)) return fail(c, JXL_ERR_INVALID_ARGUMENT, "upsample: bad arguments");
+    Tmp t;
+    float* dw = t.up(weights, (size_t)k * k * 25);
+    if (!dw) return fail(c, JXL_ERR_OOM, "device allocation failed");
+    const size_t n = (size_t)c->rp_h * c->rp_w;
+    for (int i = 0; i < 3; i++) {
+        if (!c->rp_tmp[i].ensure(sizeof(float) * n * k * k)) return fail(c, JXL_ERR_OOM, "device allocation failed (resident planes)");
+        launch_upsample(c->rp[i].as<float>(), c->rp_h, c->rp_w, k, dw, c->rp_tmp[i].as<float>(), c->stream);
+        std::swap(c->rp[i], c->rp_tmp[i]);
+    }
+    c->rp_h *= k;
+    c->rp_w *= k;
+    return finish(c);  // the weights are freed on return
+}
+
+jxl_status jxl_planes_noise(jxl_ctx* c, int32_t group_dim, uint64_t seed0, const float lut[8], float base_corr_x, float base_corr_b) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (c->rp_h <= 0) return fail(c, JXL_ERR_STATE, "no resident planes");
+    if (!lut || group_dim < 16 || (group_dim & (group_dim - 1))) return fail(c, JXL_ERR_INVALID_ARGUMENT, "noise: bad arguments");
+    const size_t n = (size_t)c->rp_h * c->rp_w;
+    float *tmp[3], *nz[3], *pl[3];
+    for (int i = 0; i < 3; i++) {
+        if (!c->rp_tmp[i].ensure(sizeof(float) * n) || !c->rp_noise[i].ensure(sizeof(float) * n))
+            return fail(c, JXL_ERR_OOM, "device allocation failed (noise planes)");
+        tmp[i] = c->rp_tmp[i].as<float>();
+        nz[i] = c->rp_noise[i].as<float>();
+        pl[i] = c->rp[i].as<float>();
+    }
+    launch_noise_init(c->rp_h, c->rp_w, group_dim, seed0, 3, tmp, nz, c->stream);
+    const float* cn[3] = {nz[0], nz[1], nz[2]};
+    launch_noise_add(pl, cn, (int64_t)n, lut, base_corr_x, base_corr_b, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+
+jxl_status jxl_planes_xyb(jxl_ctx* c, const float matrix[9], const float opsin_bias[3], const float cbrt_opsin_bias[3], float intensity_target) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (c->rp_h <= 0) return fail(c, JXL_ERR_STATE, "no resident planes");
+    if (!matrix || !opsin_bias || !cbrt_opsin_bias) return fail(c, JXL_ERR_INVALID_ARGUMENT, "xyb: bad arguments");
+    float* pl[3] = {c->rp[0].as<float>(), c->rp[1].as<float>(), c->rp[2].as<float>()};
+    launch_xyb(pl, (int64_t)c->rp_h * c->rp_w, make_xyb(matrix, opsin_bias, cbrt_opsin_bias, intensity_target), c->stream);
+    return JXL_OK;
+}
+
+jxl_status jxl_planes_ycbcr(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (c->rp_h <= 0) return fail(c, JXL_ERR_STATE, "no resident planes");
+    float* pl[3] = {c->rp[0].as<float>(), c->rp[1].as<float>(), c->rp[2].as<float>()};
+    launch_ycbcr(pl, (int64_t)c->rp_h * c->rp_w, c->stream);
+    return JXL_OK;
+}
+
+jxl_status jxl_planes_download(jxl_ctx* c, float* const out[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (c->rp_h <= 0) return fail(c, JXL_ERR_STATE, "no resident planes");
+    if (!out || !out[0] || !out[1] || !out[2]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane");
+    if ((st = finish(c))) return st;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpy(out[i], c->rp[i].p, sizeof(float) * (size_t)c->rp_h * c->rp_w, hipMemcpyDeviceToHost));
+    return JXL_OK;
+}
+
+jxl_status jxl_planes_upload(jxl_ctx* c, const float* const in[3], int32_t height, int32_t width) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!in || !in[0] || !in[1] || !in[2] || height <= 0 || width <= 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "planes: bad arguments");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) {
+        if (!c->rp[i].ensure(sizeof(float) * (size_t)height * width)) return fail(c, JXL_ERR_OOM, "device allocation failed (resident planes)");
+        HIP_TRY(c, hipMemcpy(c->rp[i].p, in[i], sizeof(float) * (size_t)height * width, hipMemcpyHostToDevice));
+    }
+    c->rp_h = height;
+    c->rp_w = width;
     return JXL_OK;
 }
 

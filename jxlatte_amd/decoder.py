@@ -322,7 +322,12 @@ class DeviceBackend:
     def close(self):
         self.ctx.close()
 
-    def vardct(self, params, weights, woffs, lfgroups, groups):
+    resident = True  # vardct(keep=(h, w)) / keep_planes(planes) hand back host.ResidentPlanes
+
+    def keep_planes(self, planes):
+        return self.host.ResidentPlanes.upload(self.ctx, planes)
+
+    def vardct(self, params, weights, woffs, lfgroups, groups, keep=None):
         fr = self.host.Frame(self.ctx, params, weights, woffs)
         for g in lfgroups:
             fr.setLFGroup(g)
@@ -331,6 +336,8 @@ class DeviceBackend:
                                    g["b_factor_lf"], g["adaptive_smoothing"])
         for pass_, grp, q in groups:
             fr.putGroup(pass_, grp, q)
+        if keep is not None:  # the planes stay on the device for the stages after decodeFrame: host.ResidentPlanes
+            return fr.keepPlanes(*keep)
         return fr.decodeFrame()
 
     def gab(self, planes, w1, w2):
@@ -588,11 +595,73 @@ class JXLDecoder:
                                    p44=None if q["p44"] is None else [list(r) for r in q["p44"]]))
         return hfglobal.generate_weights(params)
 
-    def _vardct_frame(self, fr, fuse_xyb):
+    def _vardct_frame(self, fr, fuse_xyb, keep=None):
         p, weights, woffs, lfgroups, groups, hist = self._vardct_inputs(fr, fuse_xyb)
-        planes = self.backend.vardct(p, weights, woffs, lfgroups, groups())
         self.stats[-1]["varblocks"] = {abi.TT_NAME[t]: int(n) for t, n in enumerate(hist) if n}
+        if keep is not None:
+            return self.backend.vardct(p, weights, woffs, lfgroups, groups(), keep=keep)
+        planes = self.backend.vardct(p, weights, woffs, lfgroups, groups())
         return [np.ascontiguousarray(planes[c]) for c in range(3)]
+
+    def _up_weights(self, k):
+        info = self.info
+        idx = {2: 0, 4: 1, 8: 2}[k]
+        if info.custom_up[idx]:
+            packed = self.fe.up_weights(idx)
+        else:
+            from .upweights import DEFAULT_UP
+            packed = DEFAULT_UP[k]
+        from . import host
+        return host.getUpWeights(k, packed)
+
+    def _chained_tail(self, fr, rp, buffers, colors, save, xyb_done):
+        """Frame.upsample .. performColorTransforms (JXLCodestreamDecoder.java:628-637) of the three colour planes with the
+        samples moving between host and device only where the next stage lives on the other side: upsampling, noise and the
+        colour transforms are device stages on host.ResidentPlanes; the saveBeforeCT reference, patches and splines are host
+        stages (as in the reference). `rp` is the VarDCT frame's resident result, or None when the colour planes start as the
+        host arrays buffers[:3] (Modular frames). The extra channels in buffers[3:] are host arrays throughout."""
+        info, be = self.info, self.backend
+        moves = []
+
+        def on_device():
+            nonlocal rp
+            if rp is None:  # every device stage works on float samples (Frame.java:221, :806; JXLCodestreamDecoder.java:262)
+                rp = be.keep_planes(np.stack([self._to_float(buffers[c], info.bits_per_sample) for c in range(3)]))
+                moves.append("h2d")
+            return rp
+
+        def on_host():
+            nonlocal rp
+            if rp is not None:
+                planes = rp.download()
+                for c in range(3):
+                    buffers[c] = planes[c]
+                rp = None
+                moves.append("d2h")
+
+        if fr.upsampling > 1:
+            on_device().upsample(fr.upsampling, self._up_weights(fr.upsampling))
+        if save and fr.save_before_ct:
+            on_host()
+            self.reference[fr.save_as_reference] = [b.copy() for b in buffers]
+        if fr.num_patches:
+            on_host()
+            self._patches(fr, buffers, colors)
+        if fr.has_splines:
+            on_host()
+            for c in range(3):
+                buffers[c] = self._to_float(buffers[c], info.bits_per_sample).copy()
+            render_splines(buffers, self.fe.splines(), fr.base_corr_x, fr.base_corr_b, buffers[0].shape[1], buffers[0].shape[0])
+        if fr.has_noise:  # initializeNoise depends on the frame counters and the size only: its place before the patches is moot
+            on_device().noise(fr.group_dim, (self.visibleFrames << 32) | self.invisibleFrames, np.array(fr.noise, F),
+                              fr.base_corr_x, fr.base_corr_b)
+        if info.xyb_encoded and not xyb_done:
+            m, bias, cbrt = self._opsin()
+            on_device().invertXYB(m, bias, cbrt, info.intensity_target)
+        if fr.do_ycbcr:
+            on_device().ycbcr()
+        on_host()
+        self.stats[-1]["plane_moves"] = moves
 
     def _vardct_inputs(self, fr, fuse_xyb):
         """the boundary tensors of one VarDCT frame: (jxl_vardct_params, weights, offsets, LF groups, group iterator)"""
@@ -817,12 +886,21 @@ class JXLDecoder:
                     is_float = info.ec_exp_bits[c - colors] != 0
                 buffers.append(np.zeros((ph, pw), F if is_float else np.int32))
             xyb_done = False
+            rp = None
+            resident = getattr(be, "resident", False) and colors == 3  # row f4: the stages after decodeFrame chained on the device
             if fr.encoding == VARDCT:
                 fuse_xyb = bool(info.xyb_encoded) and simple
-                planes = self._vardct_frame(fr, fuse_xyb)
-                xyb_done = fuse_xyb
-                for c in range(3):
-                    buffers[c] = planes[c]
+                # frames with stages between decodeFrame and the colour transform keep their colour planes on the device
+                # through those stages (row f4); LF frames / lfBuffer consumers need the padded planes on the host
+                if not simple and resident and fr.lf_level == 0 and fr.type != LF_FRAME:
+                    rp = self._vardct_frame(fr, False, keep=(fr.height, fr.width))
+                    for c in range(3):
+                        buffers[c] = np.zeros((fr.height, fr.width), F)  # stand-ins until the chained tail downloads
+                else:
+                    planes = self._vardct_frame(fr, fuse_xyb)
+                    xyb_done = fuse_xyb
+                    for c in range(3):
+                        buffers[c] = planes[c]
             self._modular_buffers(fr, buffers, colors)
             if fr.encoding == MODULAR and (fr.gab or fr.epf_iters > 0):
                 # Frame.performGabConvolution casts integer colour planes to float first (Frame.java:519:
@@ -858,25 +936,21 @@ class JXLDecoder:
             # Frame.upsample
             for c in range(len(buffers)):
                 k = fr.upsampling if c < colors else fr.ec_upsampling[c - colors]
-                if k > 1:
-                    idx = {2: 0, 4: 1, 8: 2}[k]
-                    if info.custom_up[idx]:
-                        packed = self.fe.up_weights(idx)
-                    else:
-                        from .upweights import DEFAULT_UP
-                        packed = DEFAULT_UP[k]
-                    from . import host
-                    wts = host.getUpWeights(k, packed)
+                if k > 1 and not (resident and c < 3):
+                    wts = self._up_weights(k)
                     depth = info.bits_per_sample if c < colors else info.ec_bits[c - colors]
                     buffers[c] = be.upsample(self._to_float(buffers[c], depth), k, wts)
             noise = None
-            if fr.has_noise:
+            if resident:
+                self._chained_tail(fr, rp, buffers, colors, save, xyb_done)
+            elif fr.has_noise:
                 h, w = buffers[0].shape
                 noise = be.noise_init(h, w, (self.visibleFrames << 32) | self.invisibleFrames, fr.group_dim, colors)
-            if save and fr.save_before_ct:
+            if not resident and save and fr.save_before_ct:
                 self.reference[fr.save_as_reference] = [b.copy() for b in buffers]
-            self._patches(fr, buffers, colors)
-            if fr.has_splines:  # Frame.renderSplines (host-side, as in the reference)
+            if not resident:
+                self._patches(fr, buffers, colors)
+            if not resident and fr.has_splines:  # Frame.renderSplines (host-side, as in the reference)
                 for c in range(3):
                     buffers[c] = self._to_float(buffers[c], info.bits_per_sample).copy()
                 render_splines(buffers, self.fe.splines(), fr.base_corr_x, fr.base_corr_b, buffers[0].shape[1], buffers[0].shape[0])
@@ -886,7 +960,7 @@ class JXLDecoder:
                 for c in range(3):
                     buffers[c] = np.ascontiguousarray(planes[c])
             # performColorTransforms
-            if (info.xyb_encoded and not xyb_done) or fr.do_ycbcr:
+            if not resident and ((info.xyb_encoded and not xyb_done) or fr.do_ycbcr):
                 planes = np.stack([self._to_float(buffers[c], info.bits_per_sample) for c in range(3)])
                 if info.xyb_encoded and not xyb_done:
                     m, bias, cbrt = self._opsin()

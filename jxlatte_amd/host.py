@@ -227,6 +227,13 @@ class Frame:
     def lastLaunchCount(self):
         return self.ctx.lib.jxl_vardct_last_launch_count(self.ctx.h)
 
+    def keepPlanes(self, height, width):
+        """run, and keep the height x width window of the result on the device for the stages that follow decodeFrame
+        (JXLCodestreamDecoder.java:628-637): -> ResidentPlanes"""
+        self.run()
+        self.ctx.call("jxl_planes_from_frame", height, width)
+        return ResidentPlanes(self.ctx)
+
     @classmethod
     def from_synth(cls, ctx, frame, stages=None, via_groups=True):
         """feed a synth.make_vardct_frame dict through the boundary exactly as the Java host would:
@@ -241,6 +248,56 @@ class Frame:
         for grp in range(synth.num_groups(frame)):
             fr.putGroup(0, grp, synth.group_view(frame, grp))
         return fr
+
+
+class ResidentPlanes:
+    """the frame's three colour planes on the device between decodeFrame and the blend: Frame.upsample (Frame.java:217-260),
+    initializeNoise + synthesizeNoise (:748-831), performColorTransforms (JXLCodestreamDecoder.java:256-276), in the
+    reference's order, with the host hook (download / upload) only where the reference's host-side stages (patches,
+    splines, saveBeforeCT) need the samples."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    @classmethod
+    def upload(cls, ctx, planes):
+        pl = _planes(planes, np.float32)
+        ctx.call("jxl_planes_upload", _p3(pl, C.c_float), pl[0].shape[0], pl[0].shape[1])
+        return cls(ctx)
+
+    @property
+    def shape(self):
+        h, w = C.c_int32(), C.c_int32()
+        self.ctx.call("jxl_planes_shape", C.byref(h), C.byref(w))
+        return h.value, w.value
+
+    def upsample(self, k, upWeights):
+        w = np.ascontiguousarray(upWeights, np.float32)
+        assert w.size == k * k * 25
+        self.ctx.call("jxl_planes_upsample", k, abi.fptr(w))
+
+    def noise(self, groupDim, seed0, lut, baseCorrelationX, baseCorrelationB):
+        lut = np.ascontiguousarray(lut, np.float32)
+        assert lut.size == 8
+        self.ctx.call("jxl_planes_noise", groupDim, C.c_uint64(seed0), abi.fptr(lut), C.c_float(baseCorrelationX),
+                      C.c_float(baseCorrelationB))
+
+    def invertXYB(self, matrix, opsin_bias, cbrt_opsin_bias, intensityTarget):
+        m = OpsinInverseMatrix(matrix, opsin_bias, cbrt_opsin_bias)
+        self.ctx.call("jxl_planes_xyb", abi.f9(*m.matrix), abi.f3(*m.opsinBias), abi.f3(*m.cbrtOpsinBias), C.c_float(intensityTarget))
+
+    def ycbcr(self):
+        self.ctx.call("jxl_planes_ycbcr")
+
+    def download(self):
+        h, w = self.shape
+        out = np.empty((3, h, w), np.float32)
+        self.ctx.call("jxl_planes_download", _p3(out, C.c_float))
+        return out
+
+    def replace(self, planes):
+        pl = _planes(planes, np.float32)
+        self.ctx.call("jxl_planes_upload", _p3(pl, C.c_float), pl[0].shape[0], pl[0].shape[1])
 
 
 class ModularChannel:

@@ -346,3 +346,11 @@ def test_lf_from_lf_frame_region_and_cast():
     ints = [rng.integers(0, 1024, (260, 260)).astype(np.int32) for _ in range(3)]
     gi = lf_from_lf_frame(ints, 0, 0, 8, 8, [0, 0, 0], [0, 0, 0], 10)
     assert np.array_equal(gi[1], (ints[1][:8, :8].astype(np.float32) * (np.float32(1) / np.float32(1023))).astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_wb_rainbow_colour_planes_cross_the_bus_once_each_way(device_backend):
+    """row f4 chained: frame 0 (2x upsampling + noise) uploads its Modular colour planes once and downloads the result once;
+    the other frames have host stages only (splines, as in the reference; the image is not XYB-encoded): nothing moves"""
+    dec, _ = decode("wb-rainbow", device_backend)
+    assert [s["plane_moves"] for s in dec.stats] == [["h2d", "d2h"], [], [], [], []]

@@ -395,3 +395,71 @@ def test_frame_interleaved_output(ctx, orc, fmt, tf, size):
     g2 = host.Frame.from_synth(ctx, small, stages=31).decodeFrame()
     small["params"].out_format = planar_fmt
     assert np.array_equal(g2, np.moveaxis(host.Frame.from_synth(ctx, small, stages=31).decodeFrame(), 0, -1))
+
+
+# ---- row f4 chained on the device: host.ResidentPlanes ----------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+@pytest.mark.parametrize("size", [(96, 64), (72, 40)])
+def test_resident_planes_chain_equals_stage_by_stage(ctx, orc, k, size):
+    """a VarDCT frame's planes kept on the device through upsample -> noise -> XYB (JXLCodestreamDecoder.java:628-637) equal
+    the oracle applying the same stages to the frame's result, bit for bit; the window is the unpadded frame size"""
+    from jxlatte_amd import host, synth
+    fr = synth.make_vardct_frame(size[0], size[1], seed=size[0] * 3 + k, aligned=False)
+    stages = abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF
+    h, w = size[1] - 3, size[0] - 5  # Frame bounds smaller than the padded size
+    rng = np.random.default_rng(k + size[0])
+    p = fr["params"]
+    m = [p.opsin_matrix[i] for i in range(9)]
+    ob = [p.opsin_bias[i] for i in range(3)]
+    cb = [p.cbrt_opsin_bias[i] for i in range(3)]
+    lut = (rng.random(8) * 0.2).astype(np.float32)
+    seed = (5 << 32) | 3
+    rp = host.Frame.from_synth(ctx, fr, stages=stages).keepPlanes(h, w)
+    assert rp.shape == (h, w)
+    exp = np.ascontiguousarray(orc.vardct_frame(fr, stages=stages)[:, :h, :w])
+    assert_bits_equal(rp.download(), exp, "window", any_nan=True)
+    if k > 1:
+        n = {2: 15, 4: 55, 8: 210}[k]
+        wts = orc.upsampling_weights(k, (rng.standard_normal(n) * 0.2).astype(np.float32))
+        rp.upsample(k, wts)
+        exp = np.stack([orc.upsample(np.ascontiguousarray(exp[c]), k, wts) for c in range(3)])
+        assert rp.shape == (h * k, w * k)
+    rp.noise(256, seed, lut, p.base_corr_x, p.base_corr_b)
+    exp = orc.noise_add(exp, orc.noise_init(h * k, w * k, seed, 256, 3), lut, p.base_corr_x, p.base_corr_b)
+    # the host hook: down, a host-side edit (stands for patches / splines), up again
+    mid = rp.download()
+    assert_bits_equal(mid, exp, "after noise", any_nan=True)
+    mid[:, ::7, ::5] += np.float32(0.125)
+    exp[:, ::7, ::5] += np.float32(0.125)
+    rp.replace(mid)
+    rp.invertXYB(m, ob, cb, p.intensity_target)
+    exp = orc.xyb(exp, m, ob, cb, p.intensity_target)
+    assert_bits_equal(rp.download(), exp, "after XYB", any_nan=True)
+    rp.ycbcr()
+    assert_bits_equal(rp.download(), orc.ycbcr(exp), "after YCbCr", any_nan=True)
+
+
+@pytest.mark.gpu
+def test_resident_planes_errors(ctx):
+    from jxlatte_amd import _lib, host, synth
+    c2 = _lib.Context(0)
+    try:
+        with pytest.raises(_lib.JxlError):
+            host.ResidentPlanes(c2).download()  # nothing resident
+        with pytest.raises(_lib.JxlError):
+            c2.call("jxl_planes_from_frame", 8, 8)  # nothing run
+        fr = synth.make_vardct_frame(64, 64, seed=1)
+        fr["params"].transfer, fr["params"].out_format = abi.TRANSFER_SRGB, abi.OUT_U8
+        f = host.Frame.from_synth(c2, fr, stages=31)
+        with pytest.raises(_lib.JxlError):
+            f.keepPlanes(64, 64)  # integer result: not a set of float planes
+        fr["params"].transfer, fr["params"].out_format = abi.TRANSFER_NONE, abi.OUT_F32
+        f = host.Frame.from_synth(c2, fr, stages=7)
+        with pytest.raises(_lib.JxlError):
+            f.keepPlanes(65, 64)  # window outside the frame
+        rp = f.keepPlanes(64, 64)
+        with pytest.raises(_lib.JxlError):
+            rp.ctx.call("jxl_planes_upsample", 3, None)
+    finally:
+        c2.close()
