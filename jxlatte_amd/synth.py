@@ -192,6 +192,8 @@ def make_vardct_frame(width, height, seed=1234, mix="default", aligned=True, par
     """
     assert width % 8 == 0 and height % 8 == 0
     rng = np.random.default_rng(seed)
+    if isinstance(mix, str) and "=" in mix:  # explicit shares: "DCT8=0.5+DCT16=0.5"
+        mix = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in mix.split("+")}
     mixd = MIXES[mix] if isinstance(mix, str) else mix
     bh, bw = height // 8, width // 8
     sel, blocks = _draw_tiling(rng, bh, bw, mixd, aligned)

@@ -110,5 +110,7 @@ for t in types:
             os.makedirs(os.path.dirname(args.stamps) or ".", exist_ok=True)
             np.savez_compressed(args.stamps.replace(".npz", "_%s.npz" % t), stamps=st)
 for m in [m for m in args.mixes.split(",") if m]:
-    frame = synth.make_vardct_frame(W, H, seed=1234, mix=m)
+    # a named mix, or an explicit one: DCT8=0.5+DCT16=0.5
+    mix = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in m.split("+")} if "=" in m else m
+    frame = synth.make_vardct_frame(W, H, seed=1234, mix=mix)
     measure(frame, "mix:" + m)
