@@ -50,6 +50,19 @@ public final class NativeBackend implements AutoCloseable {
         runBatch0(h);
     }
     private static native void runBatch0(long[] ctxs);
+    /** Binning, chroma-from-luma masks and side-table upload of the frame that was just described (setLFGroup calls done);
+     *  run() does the same on first use. Lets the host overlap this with the entropy decoding of the HF groups. */
+    public native void prepare();                                  // jxl_vardct_prepare
+
+    // ---- the stages between decodeFrame and the blend on planes that stay on the device (JXLCodestreamDecoder.java:628-637)
+    public native void planesFromFrame(int height, int width);     // jxl_planes_from_frame (after run(); header.bounds size)
+    public native void planesUpload(ByteBuffer p0, ByteBuffer p1, ByteBuffer p2, int height, int width); // jxl_planes_upload
+    public native void planesUpsample(int k, float[] weights);     // jxl_planes_upsample   (Frame.upsample)
+    public native void planesNoise(int groupDim, long seed0, float[] lut, float baseCorrX, float baseCorrB); // jxl_planes_noise
+    public native void planesXYB(float[] matrix, float[] opsinBias, float[] cbrtOpsinBias, float intensityTarget); // jxl_planes_xyb
+    public native void planesYCbCr();                              // jxl_planes_ycbcr
+    public native int[] planesShape();                             // jxl_planes_shape -> {height, width}
+    public native void planesDownload(ByteBuffer p0, ByteBuffer p1, ByteBuffer p2); // jxl_planes_download
     /** channels: one direct buffer per encoded channel; squeezeParams: 4 ints per step. */
     public native void modularApply(ByteBuffer[] chans, int[] widths, int[] heights, int[] squeezeParams, int rctType,
         int rctBegin, ByteBuffer[] out, int[] outWidths, int[] outHeights); // jxl_modular_apply

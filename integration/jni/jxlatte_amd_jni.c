@@ -130,6 +130,69 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(
     CHECK(jxl_vardct_read_output(c, out, stride));
 }
 
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_prepare(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_vardct_prepare(c));
+}
+
+/* ---- resident colour planes (include/jxlatte_amd.h: jxl_planes_*) ---- */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesFromFrame(JNIEnv* e, jobject self, jint h, jint w) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_planes_from_frame(c, h, w));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesUpload(JNIEnv* e, jobject self, jobject p0, jobject p1, jobject p2,
+        jint h, jint w) {
+    jxl_ctx* c = ctx_of(e, self);
+    const float* in[3] = {(const float*)ADDR(p0), (const float*)ADDR(p1), (const float*)ADDR(p2)};
+    CHECK(jxl_planes_upload(c, in, h, w));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesUpsample(JNIEnv* e, jobject self, jint k, jfloatArray weights) {
+    jxl_ctx* c = ctx_of(e, self);
+    jfloat* w = (*e)->GetFloatArrayElements(e, weights, NULL);  /* k*k*25 floats: jxl_upsampling_weights */
+    const jxl_status st = jxl_planes_upsample(c, k, w);
+    (*e)->ReleaseFloatArrayElements(e, weights, w, JNI_ABORT);
+    CHECK(st);
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesNoise(JNIEnv* e, jobject self, jint groupDim, jlong seed0,
+        jfloatArray lut, jfloat bcx, jfloat bcb) {
+    jxl_ctx* c = ctx_of(e, self);
+    float l[8];
+    (*e)->GetFloatArrayRegion(e, lut, 0, 8, l);
+    CHECK(jxl_planes_noise(c, groupDim, (uint64_t)seed0, l, bcx, bcb));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesXYB(JNIEnv* e, jobject self, jfloatArray matrix, jfloatArray bias,
+        jfloatArray cbrtBias, jfloat intensityTarget) {
+    jxl_ctx* c = ctx_of(e, self);
+    float m[9], b[3], cb[3];
+    (*e)->GetFloatArrayRegion(e, matrix, 0, 9, m);
+    (*e)->GetFloatArrayRegion(e, bias, 0, 3, b);
+    (*e)->GetFloatArrayRegion(e, cbrtBias, 0, 3, cb);
+    CHECK(jxl_planes_xyb(c, m, b, cb, intensityTarget));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesYCbCr(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_planes_ycbcr(c));
+}
+
+JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesShape(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    int32_t hw[2] = {0, 0};
+    jintArray out = (*e)->NewIntArray(e, 2);
+    if (jxl_planes_shape(c, &hw[0], &hw[1]) == JXL_OK && out) (*e)->SetIntArrayRegion(e, out, 0, 2, (const jint*)hw);
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesDownload(JNIEnv* e, jobject self, jobject p0, jobject p1, jobject p2) {
+    jxl_ctx* c = ctx_of(e, self);
+    float* out[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
+    CHECK(jxl_planes_download(c, out));
+}
+
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_runBatch0(JNIEnv* e, jclass k, jlongArray ctxs) {
     const jsize n = (*e)->GetArrayLength(e, ctxs);
     jlong h[64];
