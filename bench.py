@@ -49,6 +49,7 @@ def parse(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=4, help="distinct synthetic frames generated per rank (the rest reuse them)")
     ap.add_argument("--mix", default="default")
+    ap.add_argument("--size", default="", help="WxH override of the synthetic VarDCT frame size (diagnostics; named in config.workload)")
     ap.add_argument("--epf-iters", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0, help="0 = one HIP stream per frame context (default); 1 = all frames of a rank share one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,6 +182,8 @@ def main():
         return bench_modular(args, rank, world, local_rank, torch, dist)
 
     W, H = (3840, 2160) if args.workload == "vardct4k" else (7680, 4320)
+    if args.size:
+        W, H = (int(v) for v in args.size.lower().split("x"))
     fpg = args.frames_per_gpu
     real_stats = None
     kw = dict(epf_iters=args.epf_iters)
@@ -533,7 +536,7 @@ def end_to_end_leg(_lib, abi, host, synth, frame, device, npx):
 def bench_modular(args, rank, world, local_rank, torch, dist):
     from jxlatte_amd import _lib, host, synth
     W, H = (1920, 1080) if args.workload == "modular1080p" else (7680, 4320)
-    fpg = max(1, min(args.frames_per_gpu, 4))
+    fpg = max(1, min(args.frames_per_gpu, int(os.environ.get("JXL_BENCH_MODULAR_MAX", "4"))))
     streams, ctxs = [], []
     mod = synth.make_modular_frame(W, H, channels=3, seed=7 + rank)
     for i in range(fpg):

@@ -112,7 +112,12 @@ struct jxl_ctx {
     std::vector<FusedArgs> batch_restore_host;
     bool batch_restore_valid = false;
     std::vector<std::pair<const jxl_ctx*, uint64_t>> batch_key;
-    struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };  // cls 3 = the special 8x8 kernel
+    // cls 0 / 1 = k_idct_multi classes, 3 = the special 8x8 kernel (MultiArgs blocks in batch_args);
+    // 10 = k_llf_wg3, 11 / 12 = k_idct_wg3<false / true> (Wg3Args blocks in batch_wg3_args; grid_x of 10 = lanes)
+    struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };
+    DevBuf batch_wg3_args;
+    DevBuf wg3_items[2];       // spatially ordered item lists of the two k_idct_wg3 classes (wg3_item_table)
+    int wg3_item_count[2] = {0, 0};
     std::vector<BatchLaunch> batch_launches;
     hipEvent_t batch_ev = nullptr;
     bool timing = false;
@@ -262,10 +267,36 @@ jxl_status finalize_tables(jxl_ctx* c) {
         for (auto& l : cl)
             if (!l.segs.empty()) c->type_launches.push_back(std::move(l));
         jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel};
+        // One wave per item = 64 consecutive blocks of one type and channel. The block lists are group-major (256 x 256 px
+        // groups in raster order), so item k of every type covers about the same few groups. An 8 x 8 block's rows are 32-byte
+        // pieces of 128-byte lines whose other pieces belong to blocks of other types: launched type after type, every line is
+        // fetched once per type that touches it (measured: a frame of all nine special types 113 us against 60 us for any one
+        // of them; 8K: 46 against 150 Gpx/s). So the items are launched in spatial order instead -- sorted by the group of
+        // their first block -- and dealt to the XCDs in runs (workgroup b runs on XCD b % 8, each with its own L2): the items
+        // that share lines are in flight together on one L2.
+        struct Ord { uint32_t key; WorkItem w; };
+        std::vector<Ord> ord;
+        const int grs_c = std::max(1, (((channel < 0 ? c->bw : (c->bw >> c->sx[channel])) + 31) >> 5));
         for (int t : kSpecial)
             for (uint32_t o = 0; o < lists[t].size(); o += 64)
-                for (uint32_t ch = ch0; ch < ch1; ch++)
-                    items.push_back(WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(64, lists[t].size() - o)});
+                for (uint32_t ch = ch0; ch < ch1; ch++) {
+                    const DevBlock& b0 = lists[t][o];
+                    ord.push_back(Ord{(uint32_t)((b0.cy >> 5) * grs_c + (b0.cx >> 5)),
+                                      WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(64, lists[t].size() - o)}});
+                }
+        static const bool spatial = !(getenv("JXL_SPECIAL_SPATIAL") && atoi(getenv("JXL_SPECIAL_SPATIAL")) == 0);
+        if (spatial && ord.size() > 8) {
+            std::stable_sort(ord.begin(), ord.end(), [](const Ord& x, const Ord& y) { return x.key < y.key; });
+            static const int run = getenv("JXL_SPECIAL_RUN") ? std::max(1, atoi(getenv("JXL_SPECIAL_RUN"))) : 32;
+            std::vector<WorkItem> q[8];
+            for (size_t i = 0; i < ord.size(); i++) q[(i / (size_t)run) % 8].push_back(ord[i].w);
+            size_t longest = 0;
+            for (auto& v : q) longest = std::max(longest, v.size());
+            for (size_t i = 0; i < longest; i++)
+                for (int x = 0; x < 8; x++) items.push_back(i < q[x].size() ? q[x][i] : WorkItem{0u, 0u, 0u});  // count 0: the wave exits
+        } else {
+            for (const Ord& o : ord) items.push_back(o.w);
+        }
         sl.n_items = (int)items.size() - sl.items_off;
         if (sl.n_items > 0) c->special_launches.push_back(sl);
     };
@@ -309,6 +340,21 @@ jxl_status finalize_tables(jxl_ctx* c) {
     const size_t nc = (size_t)c->bh * c->bw, nt = (size_t)c->th * c->tw;
     if (!c->h_blocks.empty())
         HIP_TRY(c, hipMemcpyAsync(c->blocks.p, c->h_blocks.data(), sizeof(DevBlock) * c->h_blocks.size(), hipMemcpyHostToDevice, c->stream));
+    {
+        static const bool spatial = !(getenv("JXL_WG3_SPATIAL") && atoi(getenv("JXL_WG3_SPATIAL")) == 0);
+        std::vector<int> tab;
+        for (int k = 0; k < 2; k++) {
+            c->wg3_item_count[k] = 0;
+            for (const auto& tl : c->type_launches) {
+                if (tl.cls != 2 + k || !spatial) continue;
+                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, tab);
+                if (tab.empty()) continue;
+                if (!c->wg3_items[k].ensure(sizeof(int) * tab.size())) return fail(c, JXL_ERR_OOM, "device allocation failed (item list)");
+                HIP_TRY(c, hipMemcpy(c->wg3_items[k].p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+                c->wg3_item_count[k] = (int)(tab.size() / 4);
+            }
+        }
+    }
     if (!items.empty())
         HIP_TRY(c, hipMemcpyAsync(c->items.p, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->hf_mul.p, c->h_hf_mul.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
@@ -553,6 +599,9 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     if (c->llf_ev) (void)hipEventDestroy(c->llf_ev);
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     c->batch_args.release();
+    c->batch_wg3_args.release();
+    c->wg3_items[0].release();
+    c->wg3_items[1].release();
     c->batch_restore_args.release();
     for (int i = 0; i < jxl_ctx::kAux; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -885,6 +934,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             for (const auto& tl : c->type_launches)
                 if (tl.cls >= 2) {
                     wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
+                    if (c->wg3_item_count[tl.cls - 2] == wn[tl.cls - 2]) wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
                     all.insert(all.end(), tl.segs.begin(), tl.segs.end());
                 }
             if (!all.empty()) {
@@ -1089,8 +1139,6 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
 
 // frames whose IDCT stage can share launches: plain 4:4:4 frames made of the merged-launch types
 bool batchable(const jxl_ctx* c) {
-    for (const auto& tl : c->type_launches)
-        if (tl.cls >= 2) return false;  // the persistent kernel has no batched form: such frames run one by one
     return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && (c->p.stages & JXL_STAGE_IDCT);
 }
 }  // namespace
@@ -1175,12 +1223,53 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
             }
             if (bl.n_frames > 0) c0->batch_launches.push_back(bl);
         }
+        // the persistent three-channel kernels (k_idct_wg3.hip): LLF pre-pass of both classes, then the two classes
+        std::vector<Wg3Args> wg3_args;
+        static const int wg3_cap = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 768;
+        static const int wg3_cap_big = getenv("JXL_WG3_GRID_BIG") ? atoi(getenv("JXL_WG3_GRID_BIG")) : 512;
+        for (int cls : {10, 11, 12}) {
+            jxl_ctx::BatchLaunch bl{cls, 0, 0, 0, wg3_args.size() * sizeof(Wg3Args)};
+            int64_t max_n = 0;
+            for (int i = 0; i < n; i++) {
+                jxl_ctx* c = ctxs[i];
+                DevFrame f;
+                fill_dev_frame(c, f);
+                float* A[3] = {c->planeA[0].as<float>(), c->planeA[1].as<float>(), c->planeA[2].as<float>()};
+                std::vector<IdctSegment> segs;
+                for (const auto& tl : c->type_launches)
+                    if (tl.cls >= 2 && (cls == 10 || tl.cls == cls - 9)) segs.insert(segs.end(), tl.segs.begin(), tl.segs.end());
+                if (segs.empty()) continue;
+                Wg3Args a;
+                const int items = build_wg3_args(f, c->blocks.as<DevBlock>(), segs.data(), (int)segs.size(), cls == 10 ? 2 : cls - 11, A, a);
+                if (items <= 0) continue;
+                if (cls != 10 && c->wg3_item_count[cls - 11] == items) a.items = c->wg3_items[cls - 11].as<int>();
+                if (cls == 10) {
+                    const int64_t nl = wg3_llf_count(a);
+                    if (nl <= 0) continue;
+                    max_n = std::max(max_n, nl);
+                } else {
+                    max_n = std::max<int64_t>(max_n, items);
+                    bl.lds_bytes = std::max(bl.lds_bytes, wg3_lds_bytes(a));
+                }
+                wg3_args.push_back(a);
+                bl.n_frames++;
+            }
+            if (bl.n_frames <= 0) continue;
+            // persistent grids: the chip-wide cap shared between the frames of the launch
+            const int cap = cls == 11 ? wg3_cap : wg3_cap_big;
+            bl.grid_x = cls == 10 ? (int)std::min<int64_t>(max_n, INT32_MAX) : (int)std::min<int64_t>(max_n, std::max(1, (cap + bl.n_frames - 1) / bl.n_frames));
+            c0->batch_launches.push_back(bl);
+        }
         HIP_TRY(c0, hipSetDevice(c0->device));
-        if (!c0->batch_args.ensure(std::max<size_t>(sizeof(MultiArgs), host_args.size() * sizeof(MultiArgs))))
+        if (!c0->batch_args.ensure(std::max<size_t>(sizeof(MultiArgs), host_args.size() * sizeof(MultiArgs))) ||
+            !c0->batch_wg3_args.ensure(std::max<size_t>(sizeof(Wg3Args), wg3_args.size() * sizeof(Wg3Args))))
             return fail(c0, JXL_ERR_OOM, "device allocation failed (batch arguments)");
         HIP_TRY(c0, hipStreamSynchronize(c0->stream));  // an earlier batch may still be reading the old blocks
+        if (c0->n_aux > 0) HIP_TRY(c0, hipStreamSynchronize(c0->aux[0]));
         if (!host_args.empty())
             HIP_TRY(c0, hipMemcpy(c0->batch_args.p, host_args.data(), host_args.size() * sizeof(MultiArgs), hipMemcpyHostToDevice));
+        if (!wg3_args.empty())
+            HIP_TRY(c0, hipMemcpy(c0->batch_wg3_args.p, wg3_args.data(), wg3_args.size() * sizeof(Wg3Args), hipMemcpyHostToDevice));
         c0->batch_key.clear();
         for (int i = 0; i < n; i++) c0->batch_key.emplace_back(ctxs[i], ctxs[i]->tables_gen);
         c0->batch_restore_valid = false;
@@ -1197,12 +1286,27 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
         (void)hipEventRecord(c0->fork_ev, s0);
         (void)hipStreamWaitEvent(c0->aux[0], c0->fork_ev, 0);
     }
+    // as in run_frame: the special kernel (no LLF needed) and the 64-point family go to the side stream, the LLF pre-pass and
+    // the launch of everything up to 32 points to the main one; the r1 classes alternate
     int k = 0;
+    hipStream_t side = fork ? c0->aux[0] : s0;
     for (const auto& bl : c0->batch_launches) {
-        hipStream_t s = (fork && (k++ & 1)) ? c0->aux[0] : s0;
+        if (bl.cls >= 10) {
+            const Wg3Args* da = reinterpret_cast<const Wg3Args*>(static_cast<const char*>(c0->batch_wg3_args.p) + bl.offset);
+            if (bl.cls == 10) {
+                launch_llf_wg3_batch(da, bl.n_frames, bl.grid_x, s0);
+                if (fork) {
+                    (void)hipEventRecord(c0->llf_ev, s0);  // "LLF planes written"
+                    (void)hipStreamWaitEvent(side, c0->llf_ev, 0);
+                }
+            } else {
+                launch_idct_wg3_batch(da, bl.n_frames, bl.cls == 12, bl.grid_x, bl.lds_bytes, bl.cls == 12 ? side : s0);
+            }
+            continue;
+        }
         const MultiArgs* da = reinterpret_cast<const MultiArgs*>(static_cast<const char*>(c0->batch_args.p) + bl.offset);
-        if (bl.cls == 3) launch_idct_special_batch(da, bl.n_frames, bl.grid_x, s);
-        else launch_idct_multi_batch(da, bl.n_frames, bl.grid_x, bl.lds_bytes, bl.cls, s);
+        if (bl.cls == 3) launch_idct_special_batch(da, bl.n_frames, bl.grid_x, side);
+        else launch_idct_multi_batch(da, bl.n_frames, bl.grid_x, bl.lds_bytes, bl.cls, (fork && (k++ & 1)) ? side : s0);
     }
     if (fork) {
         (void)hipEventRecord(c0->join_ev[0], c0->aux[0]);

@@ -4,6 +4,7 @@
 // denormals preserved -- required for bit-exact parity with the Java reference.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include "../../include/jxlatte_amd.h"
 #include "../../include/jxl_transform_types.h"
@@ -107,14 +108,23 @@ struct Wg3Args {
     float *o0, *o1, *o2;
     int n_seg, total_items;
     int img_floats;  // floats of the largest three-channel LDS image among the segments' types (the tables follow it)
+    // optional explicit item list (16-byte records {type, first_block, n_blocks, 0}, total_items of them) in the order the
+    // workgroups should take them -- spatial, see wg3_item_table; nullptr: the items follow from the segments, type by type
+    const int* items;
     Wg3Seg seg[kMaxSeg];
 };
+// the item list of one class's segments in spatial order, dealt to the XCDs in runs (host side)
+void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out);
 bool wg3_handles(int type);
 bool wg3_big(int type);  // the 64-point family: its own launch (register / LDS class)
 int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],
                    Wg3Args& a);
 void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s);
 void launch_idct_wg3(const Wg3Args& a, bool big, int grid_cap, hipStream_t s);
+int64_t wg3_llf_count(const Wg3Args& a);
+size_t wg3_lds_bytes(const Wg3Args& a);
+void launch_llf_wg3_batch(const Wg3Args* dev_args, int n_frames, int64_t max_llf, hipStream_t s);
+void launch_idct_wg3_batch(const Wg3Args* dev_args, int n_frames, bool big, int grid_x, size_t lds, hipStream_t s);
 
 // ---- launchers (defined in the kernel TUs) ---------------------------------------------------
 // One launch per register class (0: every type up to 32x32, 1: the 64-point family), 256-thread workgroups.

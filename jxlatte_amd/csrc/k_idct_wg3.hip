@@ -28,6 +28,9 @@
 //   * finalizeLLF runs as a small kernel of its own before (k_llf_wg3: one lane per LLF coefficient into the llf planes).
 // Bit-exactness: every sum keeps the reference's order, multiplies and adds are separate IEEE f32 operations.
 #include "jxl_internal.h"
+#include <cstdlib>
+#include <algorithm>
+#include <vector>
 #include "../../include/jxl_tables.h"
 
 namespace jxl {
@@ -251,6 +254,13 @@ template <int P>
 __device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
     Item it{-1, 0, 0};
     if (gi >= a.total_items) return it;
+    if (a.items) {  // explicit list (uniform index: scalar loads)
+        const auto* w = (const __attribute__((address_space(4))) int*)a.items + 4 * gi;
+        it.type = w[0];
+        it.first = w[1];
+        it.nb = w[2];
+        return it;
+    }
     int k = 0;
     while (k + 1 < a.n_seg && gi >= a.seg[k + 1].item_base) k++;
     const Wg3Seg sg = a.seg[k];
@@ -564,7 +574,7 @@ __device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int 
 #define WG3_SMALL_OCC 4
 #endif
 template <bool BIG>
-__global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const Wg3Args a) {
+__device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     constexpr int P = BIG ? 4096 : 2048, NG = P / 4 / 256;
     extern __shared__ float lds[];
     const int tid0 = threadIdx.x;
@@ -632,6 +642,19 @@ __global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const
     }
 }
 
+template <bool BIG>
+__global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const Wg3Args a) {
+    wg3_body<BIG>(a);
+}
+
+// a batch of frames in one launch (jxl_vardct_run_batch): blockIdx.y = frame, each frame's workgroups stride over that frame's
+// items; the argument blocks live in device memory and are read through the constant address space (scalar loads)
+template <bool BIG>
+__global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3_batch(const Wg3Args* __restrict__ args) {
+    typedef const __attribute__((address_space(4))) Wg3Args* cargs;
+    wg3_body<BIG>(*(const Wg3Args*)((cargs)args + blockIdx.y));
+}
+
 // finalizeLLF (HFCoefficients.java:194-229) of every block of the launch's segments, one lane per coefficient, written over
 // the block's own cells of the llf planes (a block covers exactly dctSelectHeight x dctSelectWidth cells)
 template <int H, int W>
@@ -646,7 +669,7 @@ __device__ __forceinline__ void llf_one(const Wg3Args& a, const Wg3Seg& sg, int 
     (c == 0 ? l0 : c == 1 ? l1 : l2)[(int64_t)(cy + k / DSW) * a.f.bw + cx + k % DSW] = v;
 }
 
-__global__ __launch_bounds__(256) void k_llf_wg3(const Wg3Args a, float* l0, float* l1, float* l2) {
+__device__ __forceinline__ void llf_wg3_body(const Wg3Args& a, float* l0, float* l1, float* l2) {
     int t = (int)(blockIdx.x * 256 + threadIdx.x);
     for (int k = 0; k < a.n_seg; k++) {
         const Wg3Seg sg = a.seg[k];
@@ -673,6 +696,17 @@ __global__ __launch_bounds__(256) void k_llf_wg3(const Wg3Args a, float* l0, flo
     }
 }
 
+__global__ __launch_bounds__(256) void k_llf_wg3(const Wg3Args a, float* l0, float* l1, float* l2) {
+    llf_wg3_body(a, l0, l1, l2);
+}
+
+// batch form: the llf planes are the ones the frame's own argument block names (DevFrame::llf)
+__global__ __launch_bounds__(256) void k_llf_wg3_batch(const Wg3Args* __restrict__ args) {
+    typedef const __attribute__((address_space(4))) Wg3Args* cargs;
+    const Wg3Args& a = *(const Wg3Args*)((cargs)args + blockIdx.y);
+    llf_wg3_body(a, const_cast<float*>(a.f.llf[0]), const_cast<float*>(a.f.llf[1]), const_cast<float*>(a.f.llf[2]));
+}
+
 #ifdef JXL_STAMPS
 extern "C" int jxl_debug_set_stamps3(void* dev_ptr) {
     unsigned long long* p = (unsigned long long*)dev_ptr;
@@ -681,6 +715,9 @@ extern "C" int jxl_debug_set_stamps3(void* dev_ptr) {
 #endif
 
 bool wg3_handles(int type) {
+    // experiment knob: JXL_WG3_SKIP=<bit mask of types> leaves those types to the per-channel kernels of k_idct.hip
+    static const unsigned skip = getenv("JXL_WG3_SKIP") ? (unsigned)strtoul(getenv("JXL_WG3_SKIP"), nullptr, 0) : 0u;
+    if (type < 32 && ((skip >> type) & 1u)) return false;
     switch (type) {
     case 0: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 18: case 19: case 20: return true;
     default: return false;
@@ -712,6 +749,7 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.n_seg = 0;
     a.total_items = 0;
     a.img_floats = 0;
+    a.items = nullptr;
     for (int i = 0; i < n_seg && a.n_seg < Wg3Args::kMaxSeg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
         Wg3Seg& sg = a.seg[a.n_seg++];
@@ -726,6 +764,42 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     return a.total_items;
 }
 
+// Spatial item order. Launched type after type, a line of the coefficient / output planes (128 bytes = 4 cells wide) is
+// touched once per type that owns one of its cells, megabytes apart in time: mixed frames cost 5-16 % over the sum of their
+// types at 4K (the lines come back from the memory-side cache) and more once the frame outgrows it (8K: 95 against 106 Gpx/s
+// for the same mix; batches likewise). So the items are sorted by the 256 x 256 group of their first block (the block
+// lists are group-major already, so an item's blocks are neighbours) and dealt to the XCDs in runs of about one group's
+// items: workgroup w takes items w, w + G, ...; with G a multiple of 8 item i runs on XCD i % 8, so a run's items -- the
+// ones that share lines -- are in flight together behind ONE L2.
+void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out) {
+    struct Rec { uint32_t key; int type, first, nb; };
+    std::vector<Rec> recs;
+    static const int rsh = getenv("JXL_WG3_REGION_SHIFT") ? std::min(12, std::max(0, atoi(getenv("JXL_WG3_REGION_SHIFT")))) : 5;
+    const int grs = std::max(1, (frame_bw + (1 << rsh) - 1) >> rsh);
+    for (int i = 0; i < n_seg; i++) {
+        if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
+        const int nb = wg3_blocks_per_item(segs[i].type);
+        for (int o = 0; o < segs[i].n_blocks; o += nb) {
+            const DevBlock& b0 = hb[segs[i].first_block + o];
+            recs.push_back(Rec{(uint32_t)((b0.cy >> rsh) * grs + (b0.cx >> rsh)), segs[i].type, segs[i].first_block + o, std::min(nb, segs[i].n_blocks - o)});
+        }
+    }
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
+    static const int run = getenv("JXL_WG3_RUN") ? std::max(1, atoi(getenv("JXL_WG3_RUN"))) : 24;
+    std::vector<const Rec*> q[8];
+    for (size_t i = 0; i < recs.size(); i++) q[(i / (size_t)run) % 8].push_back(&recs[i]);
+    size_t longest = 0;
+    for (auto& v : q) longest = std::max(longest, v.size());
+    out.clear();
+    out.reserve(recs.size() * 4);
+    for (size_t i = 0; i < longest; i++)
+        for (int x = 0; x < 8; x++)
+            if (i < q[x].size()) {
+                const Rec& r = *q[x][i];
+                out.push_back(r.type); out.push_back(r.first); out.push_back(r.nb); out.push_back(0);
+            }
+}
+
 // LLF coefficients of the class's blocks into the llf planes (must precede launch_idct_wg3 on the same stream)
 void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s) {
     int64_t n = 0;
@@ -733,6 +807,34 @@ void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s) {
         if (a.seg[k].type != 0) n += (int64_t)a.seg[k].n_blocks * 3 * (JXL_TT[a.seg[k].type].ph / 8) * (JXL_TT[a.seg[k].type].pw / 8);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_llf_wg3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, llf[0], llf[1], llf[2]);
+}
+
+int64_t wg3_llf_count(const Wg3Args& a) {
+    int64_t n = 0;
+    for (int k = 0; k < a.n_seg; k++)
+        if (a.seg[k].type != 0) n += (int64_t)a.seg[k].n_blocks * 3 * (JXL_TT[a.seg[k].type].ph / 8) * (JXL_TT[a.seg[k].type].pw / 8);
+    return n;
+}
+
+size_t wg3_lds_bytes(const Wg3Args& a) { return sizeof(float) * ((size_t)a.img_floats + 3 * 64); }
+
+// batch forms: dev_args[0..n_frames) in device memory; max_llf = the largest wg3_llf_count, grid_x workgroups per frame,
+// lds = the largest wg3_lds_bytes among the frames
+void launch_llf_wg3_batch(const Wg3Args* dev_args, int n_frames, int64_t max_llf, hipStream_t s) {
+    if (n_frames <= 0 || max_llf <= 0) return;
+    hipLaunchKernelGGL(k_llf_wg3_batch, dim3((unsigned)((max_llf + 255) / 256), n_frames), dim3(256), 0, s, dev_args);
+}
+
+void launch_idct_wg3_batch(const Wg3Args* dev_args, int n_frames, bool big, int grid_x, size_t lds, hipStream_t s) {
+    if (n_frames <= 0 || grid_x <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_wg3_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_wg3_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    if (big) hipLaunchKernelGGL(k_idct_wg3_batch<true>, dim3(grid_x, n_frames), dim3(256), lds, s, dev_args);
+    else hipLaunchKernelGGL(k_idct_wg3_batch<false>, dim3(grid_x, n_frames), dim3(256), lds, s, dev_args);
 }
 
 // grid_cap: workgroups to launch at most (persistent; never more than there are items)
