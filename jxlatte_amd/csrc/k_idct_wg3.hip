@@ -74,9 +74,28 @@ __device__ __forceinline__ int clog2(int x) {
     return l;
 }
 
+// the two launch classes: everything up to 32 points (2048 sample positions per item and channel, 256 threads) and the
+// 64-point family (4096 positions; 512 threads, so that a lane still holds 2 coefficient groups per channel and 8 outputs
+// per pass: the 256-thread form needed 228 VGPRs -- 2 waves per SIMD and no room beside the other class's workgroups -- and
+// its single items, 100 per 4K frame of the default mix, ran 33 us each)
+#ifndef WG3_BIG_T
+#define WG3_BIG_T 512
+#endif
+template <bool BIG>
+struct Cls {
+    static constexpr int T = BIG ? WG3_BIG_T : 256;   // threads per workgroup
+    static constexpr int P = BIG ? 4096 : 2048;       // sample positions per item and channel
+    static constexpr int NG = P / 4 / T;              // 4-sample groups per lane and channel
+    // weight-row slots per lane: the groups of a lane sit at the same place of different blocks (one slot) unless a block
+    // has more groups than the workgroup has lanes
+    static constexpr int WS = BIG ? NG : 1;
+};
+
 template <int H, int W>
 struct Cfg {
     static constexpr int MAXD = H > W ? H : W;
+    static constexpr bool BIG = MAXD > 32;
+    static constexpr int T = Cls<BIG>::T;
     static constexpr int P = MAXD <= 32 ? 2048 : 4096;  // sample positions per channel and work item
     static constexpr int NB = P / (H * W);               // varblocks per work item
     static constexpr int LD = W + 1;                     // row stride of a block image (odd: rows hit different banks)
@@ -84,16 +103,17 @@ struct Cfg {
     // consecutive blocks of a column-pass wave land on consecutive bank ranges: image size == W (mod 32) for W < 32
     static constexpr int IMG = W >= 32 ? IMG0 : IMG0 + ((W - IMG0 % 32) + 32) % 32;
     static constexpr int GPB = H * W / 4;                // 4-sample groups per block
-    static constexpr int NG = P / 4 / 256;               // groups per lane and channel: 2 or 4
-    static constexpr int CH_COL = 256 / (NB * W), KC_COL = H / CH_COL;  // column pass: lane groups per column, outputs per lane
-    static constexpr int CH_ROW = 256 / (NB * H), KC_ROW = W / CH_ROW;
+    static constexpr int NG = P / 4 / T;                 // groups per lane and channel
+    static constexpr int WS = Cls<BIG>::WS;
+    static constexpr int CH_COL = T / (NB * W), KC_COL = H / CH_COL;  // column pass: lane groups per column, outputs per lane
+    static constexpr int CH_ROW = T / (NB * H), KC_ROW = W / CH_ROW;
     static constexpr int DSH = H / 8, DSW = W / 8;       // dctSelect size = LLF corner
     static constexpr int PER_B = 3 * DSH * DSW;          // LLF coefficients per block
     static constexpr int NLLF = NB * PER_B;              // ... per item (<= 192)
     static_assert(NB >= 1 && NB * W >= 64 && NB * H >= 64, "lane groups of a pass are whole waves");
     static_assert(KC_COL == 8 || KC_COL == 16, "8 or 16 outputs per lane");
     static_assert(KC_ROW == 8 || KC_ROW == 16, "8 or 16 outputs per lane");
-    static_assert(NLLF <= 256, "one LLF coefficient per lane");
+    static_assert(NLLF <= T, "one LLF coefficient per lane");
 };
 
 // KC outputs of one 1-D IDCT for three channels at once: lo[j] = outputs (2j, 2j+1) of the lane's low run, hi[j] = their
@@ -273,10 +293,10 @@ __device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
 }
 
 // what a lane holds of an item between its prefetch and its dequantisation
-template <int NG>
+template <int NG, int WS>
 struct Raw {
     v4i q[NG][3];          // quantised coefficients of 4 consecutive x, channels X, Y, B
-    v4f w[NG == 2 ? 1 : NG][3];  // their reciprocal weights ((flip ? transposed : plain) table row); with 2048 positions per
+    v4f w[WS][3];          // their reciprocal weights ((flip ? transposed : plain) table row); with 2048 positions per
                            // item a block has at most 256 groups, so both groups of a lane sit at the same place of their blocks
     float kx[NG], kb[NG];  // CfL factors of the group's 64x64 tile (0 where the reference's cache reads 0)
     float hfm[NG];         // (float)hfMultiplier of the group's block
@@ -291,7 +311,7 @@ struct Recs {
     int lx;                      // word 0 of the LLF lane's block
 };
 
-template <int NG>
+template <int T, int NG>
 __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int tid, Recs<NG>& rc) {
     const int H = JXL_TT[it.type < 0 ? 0 : it.type].ph, W = JXL_TT[it.type < 0 ? 0 : it.type].pw;
     const int lgGPB = __builtin_ctz(H) + __builtin_ctz(W) - 2;
@@ -300,7 +320,7 @@ __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int 
     for (int j = 0; j < NG; j++) {
         rc.gx[j] = rc.gz[j] = 0;
         rc.gw[j] = 1;
-        const int b = (tid + 256 * j) >> lgGPB;
+        const int b = (tid + T * j) >> lgGPB;
         if (it.type >= 0 && b < it.nb) {
             // three dword loads straight into the three loop-carried registers: one 16-byte load would land in a temporary
             // and have to be COPIED into them, i.e. waited for right here (a full L2 round trip per item, measured)
@@ -316,8 +336,8 @@ __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int 
 }
 
 // issue every load of item `it` this lane will need at dequantisation time (type-generic: run-time geometry)
-template <int NG>
-__device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int tid, const Recs<NG>& rc, Raw<NG>& raw) {
+template <int T, int NG, int WS>
+__device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int tid, const Recs<NG>& rc, Raw<NG, WS>& raw) {
     const DevFrame& f = a.f;
     raw.ok = 0;
     raw.llf = 0.0f;
@@ -328,13 +348,13 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     const float* wt[3] = {wtab + f.woffs[PI * 3], wtab + f.woffs[PI * 3 + 1], wtab + f.woffs[PI * 3 + 2]};
 #pragma unroll
     for (int j = 0; j < NG; j++) {
-        const int g = tid + 256 * j;
+        const int g = tid + T * j;
         const int b = g >> lgGPB, r = g & ((1 << lgGPB) - 1);
         const int n = r >> lgW4, x4 = (r & ((1 << lgW4) - 1)) << 2;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             raw.q[j][c] = v4i{0, 0, 0, 0};
-            if (NG > 2 || j == 0) raw.w[NG == 2 ? 0 : j][c] = *reinterpret_cast<const v4f*>(wt[c] + r * 4);  // row-major [n][x]: n * W + x4 = 4 r
+            if (WS > 1 || j == 0) raw.w[WS == 1 ? 0 : j][c] = *reinterpret_cast<const v4f*>(wt[c] + r * 4);  // row-major [n][x]: n * W + x4 = 4 r
         }
         raw.kx[j] = raw.kb[j] = 0.0f;
         raw.hfm[j] = 1.0f;
@@ -374,14 +394,14 @@ struct Body {
     using C = Cfg<H, W>;
 
     // ---- A. dequantise + chroma-from-luma -> LDS
-    static __device__ __forceinline__ void dequant(const Wg3Args& a, const Item& it, int tid, const Raw<C::NG>& raw, float* __restrict__ img,
+    static __device__ __forceinline__ void dequant(const Wg3Args& a, const Item& it, int tid, const Raw<C::NG, C::WS>& raw, float* __restrict__ img,
                                                    const float* __restrict__ qtab) {
         const DevFrame& f = a.f;
         const float qbn = f.quant_bias_numerator;
 #pragma unroll
         for (int j = 0; j < C::NG; j++) {
             if (!((raw.ok >> j) & 1u)) continue;
-            const int g = tid + 256 * j;
+            const int g = tid + C::T * j;
             const int b = g / C::GPB, r = g % C::GPB;
             const int n = r / (W / 4), x4 = (r % (W / 4)) * 4;
             // scaleFactor[c] / hfMultiplier (HFCoefficients.java:299)
@@ -389,7 +409,7 @@ struct Body {
             // (element access by constant index after unrolling: copying the vectors into local arrays made the compiler load
             // them as one <12 x float> and keep the whole prefetch state in scratch memory)
 #define QV(c, i) (raw.q[j][c][i])
-#define WV(c, i) (raw.w[C::NG == 2 ? 0 : j][c][i])
+#define WV(c, i) (raw.w[C::WS == 1 ? 0 : j][c][i])
             // HFCoefficients.dequantizeHFCoefficients inner expression (:309-315) through the tables: tab[a] = 0, quantBias,
             // (float)a - qbn / (float)a for a = 0, 1, 2..63, applied with the sign of q ((float)q - qbn / (float)q ==
             // -((float)|q| - qbn / (float)|q|) for q < 0 exactly: IEEE negation commutes with round-to-nearest division and
@@ -512,8 +532,9 @@ struct Body {
 };
 
 // type dispatch of the two specialised phases (workgroup-uniform scalar branch)
-template <bool BIG, int NG>
-__device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int tid, const Raw<NG>& raw, float* img, const float* qtab) {
+template <bool BIG>
+__device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int tid, const Raw<Cls<BIG>::NG, Cls<BIG>::WS>& raw, float* img,
+                                           const float* qtab) {
     if constexpr (BIG) {
         switch (it.type) {
         case 18: Body<64, 64, 18>::dequant(a, it, tid, raw, img, qtab); break;
@@ -573,9 +594,12 @@ __device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int 
 #ifndef WG3_SMALL_OCC
 #define WG3_SMALL_OCC 4
 #endif
+#ifndef WG3_BIG_OCC
+#define WG3_BIG_OCC (WG3_BIG_T == 256 ? 2 : 4)
+#endif
 template <bool BIG>
 __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
-    constexpr int P = BIG ? 4096 : 2048, NG = P / 4 / 256;
+    constexpr int P = Cls<BIG>::P, T = Cls<BIG>::T, NG = Cls<BIG>::NG, WS = Cls<BIG>::WS;
     extern __shared__ float lds[];
     const int tid0 = threadIdx.x;
     const int G = (int)gridDim.x;
@@ -588,12 +612,12 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         const int c = tid0 >> 6, aq = tid0 & 63;
         qtab[tid0] = aq == 0 ? 0.0f : aq == 1 ? a.f.quant_bias[c] : (float)aq - a.f.quant_bias_numerator / (float)aq;
     }
-    Raw<NG> raw;
+    Raw<NG, WS> raw;
     Recs<NG> rc;
-    load_recs<NG>(a, cur, tid0, rc);
-    prefetch<NG>(a, cur, tid0, rc, raw);
+    load_recs<T, NG>(a, cur, tid0, rc);
+    prefetch<T, NG, WS>(a, cur, tid0, rc, raw);
     Item nxt = item_of<P>(a, gi + G);
-    load_recs<NG>(a, nxt, tid0, rc);
+    load_recs<T, NG>(a, nxt, tid0, rc);
     // "every load issued so far has landed": an empty asm that reads the destination registers makes the compiler place the
     // wait HERE. Used (i) once before the loop -- the first item needs its data anyway, and the loop header then has no load
     // in flight on either incoming edge, so no conservative vmcnt wait is generated inside the loop -- and (ii) in every
@@ -607,7 +631,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
                          "v"(rc.gw[j]));
         }
 #pragma unroll
-        for (int j = 0; j < (NG == 2 ? 1 : NG); j++) asm volatile("" ::"v"(raw.w[j][0]), "v"(raw.w[j][1]), "v"(raw.w[j][2]));
+        for (int j = 0; j < WS; j++) asm volatile("" ::"v"(raw.w[j][0]), "v"(raw.w[j][1]), "v"(raw.w[j][2]));
         asm volatile("" ::"v"(raw.llf), "v"(rc.lx));
     };
     loads_landed();
@@ -620,16 +644,16 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         // of ALL type cases out of the item loop (some 80 loop-invariant VGPRs) and spills it
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        do_dequant<BIG, NG>(a, cur, tid, raw, img, qtab);  // the loads were issued one item ago
+        do_dequant<BIG>(a, cur, tid, raw, img, qtab);  // the loads were issued one item ago
         STAMP3(1);
         lds_barrier();
         STAMP3(2);
         // everything the next item needs from memory: in flight during both passes of this one. Its block records were
         // requested one item earlier still, so no load here waits for another.
-        prefetch<NG>(a, nxt, tid, rc, raw);
+        prefetch<T, NG, WS>(a, nxt, tid, rc, raw);
         gi += G;
         const Item nn = item_of<P>(a, gi + G);
-        load_recs<NG>(a, nn, tid, rc);
+        load_recs<T, NG>(a, nn, tid, rc);
         STAMP3(3);
         do_passes<BIG>(a, cur, tid, img, it_no, loads_landed);
         if (nxt.type < 0) break;
@@ -643,14 +667,14 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3(const Wg3Args a) {
+__global__ __launch_bounds__(Cls<BIG>::T, BIG ? WG3_BIG_OCC : WG3_SMALL_OCC) void k_idct_wg3(const Wg3Args a) {
     wg3_body<BIG>(a);
 }
 
 // a batch of frames in one launch (jxl_vardct_run_batch): blockIdx.y = frame, each frame's workgroups stride over that frame's
 // items; the argument blocks live in device memory and are read through the constant address space (scalar loads)
 template <bool BIG>
-__global__ __launch_bounds__(256, BIG ? 2 : WG3_SMALL_OCC) void k_idct_wg3_batch(const Wg3Args* __restrict__ args) {
+__global__ __launch_bounds__(Cls<BIG>::T, BIG ? WG3_BIG_OCC : WG3_SMALL_OCC) void k_idct_wg3_batch(const Wg3Args* __restrict__ args) {
     typedef const __attribute__((address_space(4))) Wg3Args* cargs;
     wg3_body<BIG>(*(const Wg3Args*)((cargs)args + blockIdx.y));
 }
@@ -833,7 +857,7 @@ void launch_idct_wg3_batch(const Wg3Args* dev_args, int n_frames, bool big, int 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_wg3_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set = true;
     }
-    if (big) hipLaunchKernelGGL(k_idct_wg3_batch<true>, dim3(grid_x, n_frames), dim3(256), lds, s, dev_args);
+    if (big) hipLaunchKernelGGL(k_idct_wg3_batch<true>, dim3(grid_x, n_frames), dim3(WG3_BIG_T), lds, s, dev_args);
     else hipLaunchKernelGGL(k_idct_wg3_batch<false>, dim3(grid_x, n_frames), dim3(256), lds, s, dev_args);
 }
 
@@ -848,7 +872,7 @@ void launch_idct_wg3(const Wg3Args& a, bool big, int grid_cap, hipStream_t s) {
     }
     const size_t lds = sizeof(float) * ((size_t)a.img_floats + 3 * 64);
     const int grid = std::max(1, std::min(a.total_items, grid_cap));
-    if (big) hipLaunchKernelGGL(k_idct_wg3<true>, dim3(grid), dim3(256), lds, s, a);
+    if (big) hipLaunchKernelGGL(k_idct_wg3<true>, dim3(grid), dim3(WG3_BIG_T), lds, s, a);
     else hipLaunchKernelGGL(k_idct_wg3<false>, dim3(grid), dim3(256), lds, s, a);
 }
 
