@@ -186,6 +186,27 @@ jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* ctx, const jxl_lfquant_desc* 
  * (PassGroup.java:174-200). */
 jxl_status jxl_vardct_put_group(jxl_ctx* ctx, int32_t pass, int32_t group,
                                 const int32_t* const q[3], const int32_t stride[3]);
+/* The same with 16-bit samples -- the wire format for the PCIe leg: quantised HF coefficients of photographic content fit
+ * int16 (|q| < 32768; the Java host checks while it fills the buffer and falls back to jxl_vardct_put_group for a group that
+ * does not), which halves the bytes of the dominant transfer. The device widens into the same int32 planes; everything
+ * downstream is identical. */
+jxl_status jxl_vardct_put_group_i16(jxl_ctx* ctx, int32_t pass, int32_t group,
+                                    const int16_t* const q[3], const int32_t stride[3]);
+/* The whole frame's coefficients in ONE page-locked buffer the library owns: the entropy decoder writes its groups in place
+ * (planes[c] is [H >> sy][W >> sx] int16 with row stride strides[c]; group g occupies the rectangle Frame.getGroupLocation /
+ * getGroupSize give it, HFCoefficients.java:64-69) and jxl_vardct_commit_coeffs_i16 moves the three planes with three DMA
+ * transfers instead of three per group (405 per 4K frame: their fixed cost, not their bytes, is what the per-group entry
+ * pays). map zero-fills the planes (the reference's `new int[..]`, HFCoefficients.java:68: only non-zero coefficients are
+ * ever written) and is valid until the next begin_frame; commit is asynchronous (jxl_vardct_run is ordered behind it) and
+ * may be followed by jxl_vardct_put_group for groups whose samples did not fit 16 bits, or for later passes. */
+jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* ctx, int16_t* planes[3], int32_t strides[3]);
+jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* ctx);
+/* Page-locked host memory for the buffers that cross the bus (coefficient planes in, pixel planes out; a JNI caller wraps it
+ * with NewDirectByteBuffer). put_group / put_group_i16 / read_output recognise such pointers: the copy is a direct DMA at
+ * bus speed instead of the runtime's staged copy out of pageable memory, and put_group returns without waiting for it
+ * (the buffer must stay untouched until jxl_vardct_run or jxl_ctx_synchronize). NULL on failure. */
+void* jxl_host_alloc(size_t bytes);
+void jxl_host_free(void* p);
 /* Host-side preparation a run needs and would otherwise do on first use: varblock binning by transform type
  * (the device counterpart of walking HFMetadata.blockList, HFCoefficients.java:76-85), the chroma-from-luma
  * cache-order masks (HFCoefficients.java:159-181), upload of the side tables, LF dequantisation jobs. Synchronous.

@@ -39,6 +39,16 @@ public final class NativeBackend implements AutoCloseable {
         int extraPrecision, float[] scaledDequant, int xFactorLF, int bFactorLF, boolean adaptiveSmoothing); // ..._lfquant
     public native void putGroup(int pass, int group, ByteBuffer qX, ByteBuffer qY, ByteBuffer qB, int strideX, int strideY,
         int strideB);                                              // jxl_vardct_put_group
+    /** int16 wire format: the caller has checked that every coefficient of the group fits (else putGroup). */
+    public native void putGroupI16(int pass, int group, ByteBuffer qX, ByteBuffer qY, ByteBuffer qB, int strideX, int strideY,
+        int strideB);                                              // jxl_vardct_put_group_i16
+    /** The frame's three int16 coefficient planes in page-locked memory the library owns (zero-filled): the entropy
+     *  decoder stores its non-zero coefficients in place (row stride = plane width), then commitCoeffsI16(). */
+    public native ByteBuffer[] mapCoeffsI16(int rowsX, int rowsY, int rowsB); // jxl_vardct_map_coeffs_i16 + NewDirectByteBuffer (rows = paddedHeight >> jpegUpsamplingY[c])
+    public native void commitCoeffsI16();                          // jxl_vardct_commit_coeffs_i16
+    /** Page-locked direct buffers for planes that cross the bus (coefficients in, pixels out). */
+    public static native ByteBuffer hostAlloc(long bytes);         // jxl_host_alloc + NewDirectByteBuffer
+    public static native void hostFree(ByteBuffer b);              // jxl_host_free(GetDirectBufferAddress(b))
     public native void finishFrame(ByteBuffer outX, ByteBuffer outY, ByteBuffer outB, long stride); // jxl_vardct_finish_frame
     /** Asynchronous form for independent frames decoded side by side (one NativeBackend each): run() enqueues the frame
      *  on its context's stream, readOutput() waits for it. runBatch hands several prepared frames to one call. */

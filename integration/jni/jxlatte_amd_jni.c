@@ -111,6 +111,42 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_putGroup(JN
     CHECK(jxl_vardct_put_group(c, pass, group, q, s));
 }
 
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_putGroupI16(JNIEnv* e, jobject self, jint pass, jint group, jobject qx,
+        jobject qy, jobject qb, jint sx, jint sy, jint sb) {
+    jxl_ctx* c = ctx_of(e, self);
+    const int16_t* q[3] = {(const int16_t*)ADDR(qx), (const int16_t*)ADDR(qy), (const int16_t*)ADDR(qb)};
+    const int32_t s[3] = {sx, sy, sb};
+    CHECK(jxl_vardct_put_group_i16(c, pass, group, q, s));
+}
+
+/* planes of the current frame (sizes from the params the caller passed to beginFrame: (H >> sy) * (W >> sx) samples each) */
+JNIEXPORT jobjectArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_mapCoeffsI16(JNIEnv* e, jobject self, jint rx, jint ry, jint rb) {
+    jxl_ctx* c = ctx_of(e, self);
+    int16_t* pl[3];
+    int32_t st[3];
+    const jint h[3] = {rx, ry, rb};
+    jxl_status r = jxl_vardct_map_coeffs_i16(c, pl, st);
+    if (r) { rethrow(e, c, r); return NULL; }
+    jobjectArray out = (*e)->NewObjectArray(e, 3, (*e)->FindClass(e, "java/nio/ByteBuffer"), NULL);
+    for (int i = 0; i < 3; i++)
+        (*e)->SetObjectArrayElement(e, out, i, (*e)->NewDirectByteBuffer(e, pl[i], (jlong)st[i] * h[i] * 2));
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_commitCoeffsI16(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_vardct_commit_coeffs_i16(c));
+}
+
+JNIEXPORT jobject JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_hostAlloc(JNIEnv* e, jclass k, jlong bytes) {
+    void* p = jxl_host_alloc((size_t)bytes);
+    return p ? (*e)->NewDirectByteBuffer(e, p, bytes) : NULL;
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_hostFree(JNIEnv* e, jclass k, jobject b) {
+    if (b) jxl_host_free((*e)->GetDirectBufferAddress(e, b));
+}
+
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_finishFrame(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
         jlong stride) {
     jxl_ctx* c = ctx_of(e, self);

@@ -116,6 +116,12 @@ struct jxl_ctx {
     // 10 = k_llf_wg3, 11 / 12 = k_idct_wg3<false / true> (Wg3Args blocks in batch_wg3_args; grid_x of 10 = lanes)
     struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };
     DevBuf batch_wg3_args;
+    void* h_map16 = nullptr;   // page-locked frame-sized int16 planes handed to the caller (jxl_vardct_map_coeffs_i16)
+    size_t h_map16_bytes = 0;
+    bool map16_valid = false;
+    DevBuf stage16;            // int16 wire format: one tile per (group, channel) (jxl_vardct_put_group_i16)
+    std::vector<float> h_weights_in;  // the last weight set handed over (set_weights skips an identical one)
+    int32_t h_woffs_in[51] = {};
     DevBuf wg3_items[2];       // spatially ordered item lists of the two k_idct_wg3 classes (wg3_item_table)
     int wg3_item_count[2] = {0, 0};
     std::vector<BatchLaunch> batch_launches;
@@ -189,6 +195,24 @@ __global__ void k_accumulate2d(int32_t* dst, int64_t dpitch, const int32_t* src,
     if (x >= gw || y >= gh) return;
     int32_t* d = dst + (int64_t)y * dpitch + x;
     *d = (int32_t)((uint32_t)*d + (uint32_t)src[(int64_t)y * gw + x]);  // PassGroup.java:174-200
+}
+
+// int16 wire format -> the int32 coefficient planes (acc: PassGroup.java:174-200, Java int wrap)
+__global__ void k_widen2d(int32_t* dst, int64_t dpitch, const int16_t* src, int gw, int gh, int acc) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= gw || y >= gh) return;
+    int32_t* d = dst + (int64_t)y * dpitch + x;
+    const int32_t v = (int32_t)src[(int64_t)y * gw + x];
+    *d = acc ? (int32_t)((uint32_t)*d + (uint32_t)v) : v;
+}
+
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc pointer: not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
 }
 
 bool is_small(int t) { return JXL_TT[t].ph == 8 && JXL_TT[t].pw == 8; }
@@ -600,6 +624,9 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     c->batch_args.release();
     c->batch_wg3_args.release();
+    c->stage16.release();
+    if (c->h_map16) (void)hipHostFree(c->h_map16);
+    c->h_map16 = nullptr;
     c->wg3_items[0].release();
     c->wg3_items[1].release();
     c->batch_restore_args.release();
@@ -681,6 +708,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     c->lf_jobs.clear();
     c->tables_dirty = true;
     c->frame_open = true;
+    c->map16_valid = false;
     c->ev_runs = 0;
     c->result[0] = c->result[1] = c->result[2] = nullptr;
     return JXL_OK;
@@ -699,6 +727,12 @@ jxl_status jxl_vardct_set_weights(jxl_ctx* c, const float* w, size_t n_floats, c
             if (o < 0 || (size_t)o + (size_t)mh * mw > n_floats) return fail(c, JXL_ERR_INVALID_ARGUMENT, "weight offset %d out of range", o);
         }
     }
+    // the same quant tables as the previous frame (the usual case inside one codestream; tables are ~1.5 MB): nothing to do
+    if (c->have_weights && c->h_weights_in.size() == n_floats && memcmp(c->h_woffs_in, offs, sizeof c->h_woffs_in) == 0 &&
+        memcmp(c->h_weights_in.data(), w, sizeof(float) * n_floats) == 0)
+        return JXL_OK;
+    c->h_weights_in.assign(w, w + n_floats);
+    memcpy(c->h_woffs_in, offs, sizeof c->h_woffs_in);
     // device layout: every matrix at a 16-byte aligned offset of the library's own (the kernels move weight rows as float4),
     // plus a transposed copy of every matrix for flip() blocks, which index w3[x][y] (HFCoefficients.java:312-314)
     int32_t doffs[51];
@@ -863,16 +897,105 @@ jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const i
         const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
         if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
         int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)((gy * 256) >> c->sy[ch]) * Wc + ((gx * 256) >> c->sx[ch]);
+        const bool pinned = is_pinned_host(q[ch]);
         if (pass == 0) {
             HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)Wc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
         } else {
             HIP_TRY(c, hipMemcpy2DAsync(c->group_tmp.p, (size_t)gwc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL(k_accumulate2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, dst, (int64_t)Wc,
                                c->group_tmp.as<int32_t>(), gwc, ghc);
+            if (pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));  // group_tmp is reused by the next plane
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller's buffer is pageable and may be reused
+        if (!pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller's buffer is pageable and may be reused
     }
     return JXL_OK;
+}
+
+jxl_status jxl_vardct_put_group_i16(jxl_ctx* c, int32_t pass, int32_t group, const int16_t* const q[3], const int32_t stride[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
+    if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
+    const int gy = group / grs, gx = group % grs;
+    const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);
+    // staging: one 256 x 256 int16 tile per (group, channel) in a ring large enough for a frame, so that the copies of a
+    // frame's groups queue up behind each other without a host wait when the source is page-locked
+    const size_t tile = (size_t)256 * 256 * sizeof(int16_t);
+    const size_t slots = (size_t)grs * gcs * 3;
+    if (!c->stage16.ensure(tile * slots)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
+    for (int ch = 0; ch < 3; ch++) {
+        const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
+        if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
+        int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)((gy * 256) >> c->sy[ch]) * Wc + ((gx * 256) >> c->sx[ch]);
+        int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + tile * ((size_t)group * 3 + ch));
+        const bool pinned = is_pinned_host(q[ch]);
+        HIP_TRY(c, hipMemcpy2DAsync(stg, (size_t)gwc * 2, q[ch], (size_t)stride[ch] * 2, (size_t)gwc * 2, ghc, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, dst, (int64_t)Wc, stg, gwc, ghc, pass > 0 ? 1 : 0);
+        if (!pinned || pass > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));  // pageable source; a later pass reuses the slot
+    }
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* c, int16_t* planes[3], int32_t strides[3]) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    if (!planes || !strides) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null argument");
+    size_t off[4] = {0, 0, 0, 0};
+    for (int ch = 0; ch < 3; ch++) off[ch + 1] = off[ch] + (((size_t)(c->W >> c->sx[ch]) * (c->H >> c->sy[ch]) * sizeof(int16_t) + 255) & ~(size_t)255);
+    if (c->h_map16_bytes < off[3]) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // an earlier commit may still be reading the old buffer
+        if (c->h_map16) (void)hipHostFree(c->h_map16);
+        c->h_map16 = nullptr;
+        c->h_map16_bytes = 0;
+        if (hipHostMalloc(&c->h_map16, off[3], hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_map16 = nullptr;
+            return fail(c, JXL_ERR_OOM, "page-locked allocation of %zu bytes failed", off[3]);
+        }
+        c->h_map16_bytes = off[3];
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    memset(c->h_map16, 0, off[3]);
+    for (int ch = 0; ch < 3; ch++) {
+        planes[ch] = reinterpret_cast<int16_t*>(static_cast<char*>(c->h_map16) + off[ch]);
+        strides[ch] = c->W >> c->sx[ch];
+    }
+    c->map16_valid = true;
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->frame_open || !c->map16_valid) return fail(c, JXL_ERR_STATE, "map_coeffs_i16 first");
+    if (!c->stage16.ensure(c->h_map16_bytes)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
+    size_t off = 0;
+    for (int ch = 0; ch < 3; ch++) {
+        const int Wc = c->W >> c->sx[ch], Hc = c->H >> c->sy[ch];
+        const size_t bytes = (size_t)Wc * Hc * sizeof(int16_t);
+        int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + off);
+        HIP_TRY(c, hipMemcpyAsync(stg, static_cast<char*>(c->h_map16) + off, bytes, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(Wc, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), (int64_t)Wc, stg,
+                           Wc, Hc, 0);
+        off += (bytes + 255) & ~(size_t)255;
+    }
+    return JXL_OK;
+}
+
+void* jxl_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void jxl_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* c, int32_t on) {

@@ -188,6 +188,31 @@ class Frame:
         strides = (C.c_int32 * 3)(*[a.shape[1] for a in q])
         self.ctx.call("jxl_vardct_put_group", pass_, group, pp, strides)
 
+    def putGroupI16(self, pass_, group, q):
+        """the int16 wire format (jxl_vardct_put_group_i16): the caller has checked that every |q| fits"""
+        q = [np.ascontiguousarray(a, np.int16) for a in q]
+        pp = (C.POINTER(C.c_int16) * 3)(*[a.ctypes.data_as(C.POINTER(C.c_int16)) for a in q])
+        strides = (C.c_int32 * 3)(*[a.shape[1] for a in q])
+        self.ctx.call("jxl_vardct_put_group_i16", pass_, group, pp, strides)
+        self._keep = getattr(self, "_keep", []) + [q]  # page-locked sources are read asynchronously: keep them alive until run()
+
+    def mapCoeffsI16(self):
+        """the frame's three coefficient planes as numpy views over the library's page-locked staging buffer
+        (jxl_vardct_map_coeffs_i16): write the groups in place, then commitCoeffsI16()"""
+        pp = (C.POINTER(C.c_int16) * 3)()
+        strides = (C.c_int32 * 3)()
+        self.ctx.call("jxl_vardct_map_coeffs_i16", pp, strides)
+        p = self.params
+        out = []
+        for c in range(3):
+            h, w = self.height >> p.jpeg_upsampling_y[c], self.width >> p.jpeg_upsampling_x[c]
+            buf = (C.c_int16 * (h * w)).from_address(C.addressof(pp[c].contents))
+            out.append(np.frombuffer(buf, dtype=np.int16).reshape(h, w))
+        return out
+
+    def commitCoeffsI16(self):
+        self.ctx.call("jxl_vardct_commit_coeffs_i16")
+
     def run(self):
         """enqueue all stages (asynchronous)"""
         self.ctx.call("jxl_vardct_run")
@@ -248,6 +273,26 @@ class Frame:
         for grp in range(synth.num_groups(frame)):
             fr.putGroup(0, grp, synth.group_view(frame, grp))
         return fr
+
+
+class PinnedArray:
+    """numpy view over page-locked host memory from jxl_host_alloc (what a JNI caller wraps with NewDirectByteBuffer): copies
+    to / from it are direct DMA, and put_group does not wait for them"""
+
+    def __init__(self, lib, shape, dtype):
+        self.lib = lib
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = lib.jxl_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise MemoryError("jxl_host_alloc(%d)" % n)
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.lib.jxl_host_free(self.ptr)
+            self.ptr = None
 
 
 class ResidentPlanes:

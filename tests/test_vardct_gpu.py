@@ -164,3 +164,74 @@ def test_sparse_coefficients_and_signed_zero_lf(ctx, orc, mix, aligned, nonzero_
         got = fr.decodeFrame()
         exp = orc.vardct_frame(frame, stages=stages)
         assert_bits_equal(got, exp, "sparse %s p=%g stages=%s" % (mix, nonzero_p, stages))
+
+
+# ---- the PCIe leg: int16 wire format and page-locked buffers ---------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_int16_wire_format_and_pinned_buffers(ctx, orc, pinned):
+    """jxl_vardct_put_group_i16 (+ page-locked sources from jxl_host_alloc, copied asynchronously) fills the same coefficient
+    planes as jxl_vardct_put_group: identical frame output, also for a second pass that accumulates (PassGroup.java:174-200)"""
+    from jxlatte_amd import _lib
+    fr = synth.make_vardct_frame(520, 264, seed=77, aligned=False)
+    assert np.abs(fr["coeff"]).max() < 32768
+    p = abi.VarDCTParams.from_buffer_copy(fr["params"])
+    p.stages = abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF
+    lib = _lib.load()
+    keep = []
+
+    def feed(use16, passes):
+        f = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+        for g in fr["lfgroups"]:
+            f.setLFGroup(g)
+        for grp in range(synth.num_groups(fr)):
+            planes = synth.group_view(fr, grp)
+            for ps in range(passes):
+                # pass 0 carries q - 3 * (passes - 1), every later pass adds 3: the sum is q
+                part = [(a - 3 * (passes - 1) if ps == 0 else np.full_like(a, 3)) for a in planes]
+                if pinned:
+                    dt = np.int16 if use16 else np.int32
+                    pa = [host.PinnedArray(lib, a.shape, dt) for a in part]
+                    for dst, a in zip(pa, part):
+                        dst.array[...] = a
+                    keep.extend(pa)
+                    part = [x.array for x in pa]
+                if use16:
+                    f.putGroupI16(ps, grp, part)
+                else:
+                    f.putGroup(ps, grp, part)
+        return f.decodeFrame()
+
+    ref = feed(False, 1)
+    assert_bits_equal(ref, orc.vardct_frame(fr, stages=p.stages), "int32 path")
+    assert_bits_equal(feed(True, 1), ref, "int16 wire format")
+    assert_bits_equal(feed(True, 2), ref, "int16, two passes")
+    assert_bits_equal(feed(False, 2), ref, "int32, two passes")
+    for x in keep:
+        x.free()
+
+
+@pytest.mark.gpu
+def test_mapped_int16_coefficient_planes(ctx, orc):
+    """jxl_vardct_map_coeffs_i16 / commit: groups written in place into the library's page-locked planes give the same frame;
+    a put_group after the commit overrides its rectangle (the int32 fallback for a group that does not fit 16 bits)"""
+    fr = synth.make_vardct_frame(520, 264, seed=78, aligned=False)
+    p = abi.VarDCTParams.from_buffer_copy(fr["params"])
+    p.stages = abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF
+    big = dict(fr)
+    big["coeff"] = fr["coeff"].copy()
+    big["coeff"][1, 3, 5] = 70000  # one sample of group 0 outside the int16 range
+    exp = orc.vardct_frame(big, stages=p.stages)
+    f = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+    for g in fr["lfgroups"]:
+        f.setLFGroup(g)
+    planes = f.mapCoeffsI16()
+    assert all(int(np.abs(a).max()) == 0 for a in planes)  # zero-filled at map time
+    for c in range(3):
+        planes[c][...] = np.clip(big["coeff"][c], -32768, 32767)
+    f.commitCoeffsI16()
+    f.putGroup(0, 0, synth.group_view(big, 0))  # group 0 again, 32-bit
+    assert_bits_equal(f.decodeFrame(), exp, "mapped int16 planes + int32 fallback group")
+    with pytest.raises(_lib.JxlError):
+        f2 = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+        f2.commitCoeffsI16()  # nothing mapped for this frame
