@@ -4,6 +4,7 @@
 #include "jxl_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -221,6 +222,14 @@ bool is_large(int t) { return JXL_TT[t].ph >= 128 || JXL_TT[t].pw >= 128; }
 // Bin the varblocks and compute the CfL cache-order masks; upload side tables.
 jxl_status finalize_tables(jxl_ctx* c) {
     if (!c->tables_dirty) return JXL_OK;
+    static const bool ptime = getenv("JXL_PREPARE_TIMING") != nullptr;  // diagnostics: host time of the sections, to stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!ptime) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[prepare] %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     const int lrs = ceil_div(c->W, 2048), lcs = ceil_div(c->H, 2048);
     for (int i = 0; i < lrs * lcs; i++)
         if (!c->lfg_set[i]) return fail(c, JXL_ERR_STATE, "LF group %d was never set", i);
@@ -228,17 +237,32 @@ jxl_status finalize_tables(jxl_ctx* c) {
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     // reference visiting order: groups in raster order (Frame.java:367-373), inside a group the LF group's
     // blockList order filtered by the group (HFCoefficients.java:76-85)
-    std::vector<std::vector<DevBlock>> per_group((size_t)grs * gcs);
+    // counting sort by group (stable: keeps the block-list order inside a group), and the per-type counts on the way
+    const int n_groups = grs * gcs;
+    std::vector<uint32_t> g_off((size_t)n_groups + 1, 0);
+    size_t t_count[JXL_NUM_TRANSFORM_TYPES] = {};
+    size_t n_all = 0;
     for (int li = 0; li < lrs * lcs; li++) {
+        n_all += c->lfg_blocks[li].size();
         for (const DevBlock& b : c->lfg_blocks[li]) {
-            const int g = (b.cy >> 5) * grs + (b.cx >> 5);
-            per_group[g].push_back(b);
+            g_off[(size_t)((b.cy >> 5) * grs + (b.cx >> 5)) + 1]++;
+            t_count[b.type]++;
         }
     }
+    for (int g = 0; g < n_groups; g++) g_off[(size_t)g + 1] += g_off[g];
+    std::vector<DevBlock> by_group(n_all);
+    {
+        std::vector<uint32_t> pos(g_off.begin(), g_off.end() - 1);
+        for (int li = 0; li < lrs * lcs; li++)
+            for (const DevBlock& b : c->lfg_blocks[li]) by_group[pos[(size_t)((b.cy >> 5) * grs + (b.cx >> 5))]++] = b;
+    }
+    mark("blocks by group");
     std::vector<int32_t> stamp((size_t)c->th * c->tw, -1);
     std::vector<DevBlock> sm[JXL_NUM_TRANSFORM_TYPES];
-    for (int g = 0; g < grs * gcs; g++) {
-        for (DevBlock b : per_group[g]) {
+    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) sm[t].reserve(t_count[t]);
+    for (int g = 0; g < n_groups; g++) {
+        for (uint32_t bi = g_off[g]; bi < g_off[(size_t)g + 1]; bi++) {
+            DevBlock b = by_group[bi];
             const int ph = JXL_TT[b.type].ph, pw = JXL_TT[b.type].pw;
             const int py0 = b.cy * 8, px0 = b.cx * 8;
             if (py0 + ph > c->H || px0 + pw > c->W)
@@ -257,6 +281,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
             sm[b.type].push_back(b);
         }
     }
+    mark("CfL masks + bins by type");
     // layout: [8x8-footprint types..., medium types..., large types...]; expensive items first so that the
     // tail of the single launch is made of cheap workgroups. Chroma-subsampled frames (c->sub) get one such layout per
     // channel: only the blocks aligned to the channel's grid, in the channel's own cell coordinates
@@ -347,6 +372,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
             lay_out(sub_lists, ch);
         }
     }
+    mark("launch layout");
     c->large_first = (int)c->h_blocks.size();
     for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
         if (is_large(t)) c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
@@ -362,6 +388,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
         !c->items.ensure(sizeof(WorkItem) * std::max<size_t>(1, items.size())))
         return fail(c, JXL_ERR_OOM, "device allocation failed (block tables)");
     const size_t nc = (size_t)c->bh * c->bw, nt = (size_t)c->th * c->tw;
+    mark("allocations");
     if (!c->h_blocks.empty())
         HIP_TRY(c, hipMemcpyAsync(c->blocks.p, c->h_blocks.data(), sizeof(DevBlock) * c->h_blocks.size(), hipMemcpyHostToDevice, c->stream));
     {
@@ -381,6 +408,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     }
     if (!items.empty())
         HIP_TRY(c, hipMemcpyAsync(c->items.p, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, c->stream));
+    mark("block upload + item tables");
     HIP_TRY(c, hipMemcpyAsync(c->hf_mul.p, c->h_hf_mul.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->sharp.p, c->h_sharp.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
     // chroma-from-luma factor per 64x64 tile, HFCoefficients.java:177-181: base + factor / colorFactor in float (one IEEE
@@ -432,6 +460,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     for (int ch = 0; ch < 3; ch++)
         HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
+    mark("side tables + LF + sync");
     c->tables_dirty = false;
     static std::atomic<uint64_t> g_tables_gen{0};  // process-wide: a new context at a recycled address never matches an old key
     c->tables_gen = ++g_tables_gen;
