@@ -19,7 +19,7 @@ def find(sub, pat):
 
 
 def short(n):
-    n = n.replace("void ", "").replace("jxl::(anonymous namespace)::", "").replace("jxl::", "")
+    n = n.replace("void ", "").replace("jxl::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("jxl::", "")
     return n.split("(")[0]
 
 
