@@ -409,6 +409,9 @@ jxl_status jxl_modular_apply(jxl_ctx* ctx, const jxl_channel* chans, int32_t n_c
                              int32_t rct_type, int32_t rct_begin,
                              jxl_channel* out, int32_t n_out);
 int32_t    jxl_modular_last_launch_count(const jxl_ctx* ctx);
+/* how often a plan had to be run again with in-order verification because a segment boundary of the speculative run did not
+ * match (diagnostics; the result is exact either way) */
+int32_t    jxl_modular_redo_count(const jxl_ctx* ctx);
 
 #ifdef __cplusplus
 }

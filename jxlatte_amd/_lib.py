@@ -122,6 +122,7 @@ SIGNATURES = {
     "jxl_modular_apply": (i32, [vp, C.POINTER(abi.Channel), i32, C.POINTER(abi.SqueezeParam), i32, i32, i32,
                                 C.POINTER(abi.Channel), i32]),
     "jxl_modular_last_launch_count": (i32, [vp]),
+    "jxl_modular_redo_count": (i32, [vp]),
 }
 
 _lib = None

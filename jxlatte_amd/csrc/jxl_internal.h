@@ -225,6 +225,9 @@ struct SqueezeBatch {
     int n;
     int horizontal;
     SqueezeDesc d[8];
+    // k_squeeze_verify: nullptr = repair a mismatching row / column in place (the step is then exact before the next one
+    // starts); else = only report (atomicOr 1): the check runs beside the following steps and the host redoes the plan
+    int32_t* flag;
 };
 // Small steps are bound by the time ONE wave needs for its segment (~130 cycles per pair), large ones by bandwidth: the host
 // gives steps of up to 8 Mi samples 32-pair segments with an 8-pair warm-up (measured: 1080p image 0.245 -> 0.195 ms) and
@@ -234,7 +237,8 @@ __host__ __device__ inline int squeeze_warm(const SqueezeDesc& d) { return d.seg
 __host__ __device__ inline int squeeze_segments(const SqueezeDesc& d) {
     return d.side && d.rdim > squeeze_seg(d) ? (d.rdim + squeeze_seg(d) - 1) / squeeze_seg(d) : 1;
 }
-void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s);
+// check_stream / ev: with bt.flag set, the verification launch goes to check_stream behind an event recorded on s
+void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t check_stream = nullptr, hipEvent_t ev = nullptr);
 // a run of small steps in one launch: dev_steps = the steps' SqueezeBatch blocks in device memory, slot i of every step by
 // workgroup i (the caller has checked that slot i of a step depends on slot i of the step before only)
 void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slots, hipStream_t s);

@@ -275,6 +275,10 @@ __global__ __launch_bounds__(64) void k_squeeze_verify(const SqueezeBatch bt) {
     for (int s = nseg - 1; s >= 1; s--)
         if (d.side[(int64_t)s * n + i] != *po(2 * s * squeeze_seg(d) - 1)) bad = s;
     if (__builtin_expect(bad == 0, 1)) return;
+    if (bt.flag) {  // report only: the following steps have already consumed this step's output
+        atomicOr(bt.flag, 1);
+        return;
+    }
     int32_t left = *po(2 * bad * squeeze_seg(d) - 1);
     for (int k = bad * squeeze_seg(d); k < rdim; k++) {
         const int32_t a = at_a(k);
@@ -508,7 +512,7 @@ void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slot
     hipLaunchKernelGGL(k_squeeze_chain, dim3(n_slots), dim3(256), 0, s, dev_steps, n_steps);
 }
 
-void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s) {
+void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t check_stream, hipEvent_t ev) {
     if (bt.n <= 0) return;
     int maxdim = 0, nseg = 1;
     for (int i = 0; i < bt.n; i++) {
@@ -527,7 +531,15 @@ void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s) {
     if (bt.horizontal && h_lds) hipLaunchKernelGGL(k_inv_hsqueeze, grid, dim3(64), 0, s, bt);
     else if (bt.horizontal) hipLaunchKernelGGL(k_inv_squeeze_walk<true>, grid, dim3(64), 0, s, bt);
     else hipLaunchKernelGGL(k_inv_squeeze_walk<false>, grid, dim3(64), 0, s, bt);
-    if (nseg > 1) hipLaunchKernelGGL(k_squeeze_verify, dim3((maxdim + 63) / 64, bt.n), dim3(64), 0, s, bt);
+    if (nseg > 1) {
+        hipStream_t vs = s;
+        if (bt.flag && check_stream && ev) {
+            (void)hipEventRecord(ev, s);
+            (void)hipStreamWaitEvent(check_stream, ev, 0);
+            vs = check_stream;
+        }
+        hipLaunchKernelGGL(k_squeeze_verify, dim3((maxdim + 63) / 64, bt.n), dim3(64), 0, vs, bt);
+    }
 }
 
 void launch_inv_hsqueeze(const int32_t* avg, int aw, const int32_t* res, int rw, int h, int32_t* out, hipStream_t s) {

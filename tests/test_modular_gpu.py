@@ -188,3 +188,44 @@ def test_segmented_squeeze_adversarial(ctx, orc, horizontal, h_kernel):
         a, r = a.T.copy(), r.T.copy()
     got, exp = _one_step(ctx, orc, a, r, horizontal)
     assert_bits_equal(got, exp, "adversarial %s" % ("h" if horizontal else "v"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_plan_with_speculative_checks_redoes_adversarial_rows(ctx, orc, horizontal, monkeypatch):
+    """(JXL_SQUEEZE_SPECULATE=1, off by default) jxl_modular_run checks the segmented walks beside the following steps and only reports a mismatch; reading the result
+    then runs the plan again in order. Rows that never forget their start (see _adversarial) force that path: the output is
+    still the serial walk's, bit for bit, and the redo is counted. Ordinary data right after it: no redo."""
+    a, r = _adversarial(300, 70)
+    exp = orc.inv_hsqueeze(a, r)
+    if not horizontal:
+        a, r, exp = a.T.copy(), r.T.copy(), exp.T.copy()
+    sp = [(1 if horizontal else 0, 1, 0, 1)]
+    monkeypatch.setenv("JXL_SQUEEZE_SPECULATE", "1")
+    before = ctx.lib.jxl_modular_redo_count(ctx.h)
+    ms = host.ModularStream(ctx, [a, r], sp)
+    out = ms.applyTransforms()
+    assert len(out) == 1
+    assert_bits_equal(out[0], exp, "adversarial plan %s" % ("h" if horizontal else "v"))
+    assert ctx.lib.jxl_modular_redo_count(ctx.h) == before + 1
+    rng = np.random.default_rng(9)
+    a2 = rng.integers(-3000, 3000, size=a.shape).astype(np.int32)
+    r2 = np.rint(rng.laplace(0, 40, size=r.shape)).astype(np.int32)
+    exp2 = orc.inv_hsqueeze(a2, r2) if horizontal else orc.inv_hsqueeze(a2.T.copy(), r2.T.copy()).T
+    out2 = host.ModularStream(ctx, [a2, r2], sp).applyTransforms()
+    assert_bits_equal(out2[0], exp2, "ordinary plan")
+    assert ctx.lib.jxl_modular_redo_count(ctx.h) == before + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("horizontal", [True, False])
+def test_plan_default_repairs_adversarial_rows_in_order(ctx, orc, horizontal):
+    """the default plan: the verification launch of a step repairs mismatching rows before the next step starts"""
+    a, r = _adversarial(300, 70)
+    exp = orc.inv_hsqueeze(a, r)
+    if not horizontal:
+        a, r, exp = a.T.copy(), r.T.copy(), exp.T.copy()
+    before = ctx.lib.jxl_modular_redo_count(ctx.h)
+    out = host.ModularStream(ctx, [a, r], [(1 if horizontal else 0, 1, 0, 1)]).applyTransforms()
+    assert_bits_equal(out[0], exp, "adversarial plan %s" % ("h" if horizontal else "v"))
+    assert ctx.lib.jxl_modular_redo_count(ctx.h) == before
