@@ -241,7 +241,16 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                 float sc = 0.0f + nb[cy * MW + cx] * 1.0f;
 #pragma unroll
                 for (int t = 0; t < NT; t++) sc = sc + nb[(cy + TY[t]) * MW + cx + TX[t]] * dist[i][t];
+#ifdef JXL_EPF_DIV_BRANCH
                 res[c][i] = skip[i] ? nb[cy * MW + cx] : sc / sumW[i];
+#else
+                // the quotient is formed unconditionally (the empty asm keeps the optimiser from sinking the division into
+                // a branch on `skip`): twelve exec-masked blocks per stage become straight-line code, and the schedulers
+                // interleave the twelve dependent rcp / fma chains
+                float qv = sc / sumW[i];
+                asm volatile("" : "+v"(qv));
+                res[c][i] = skip[i] ? nb[cy * MW + cx] : qv;
+#endif
             }
     }
 }
