@@ -96,7 +96,7 @@ struct jxl_ctx {
     bool sub = false;      // any jpeg_upsampling shift non-zero
     int sy[3] = {0, 0, 0}, sx[3] = {0, 0, 0};
     DevBuf hfm_sub[3];     // hfMultiplier resampled onto each channel's cell grid
-    struct SpecialLaunch { int items_off, n_items, channel; };
+    struct SpecialLaunch { int items_off, n_items, channel; bool wg_items; };
     std::vector<SpecialLaunch> special_launches;
     std::vector<TypeLaunch> type_launches;
     int large_first = 0, large_count = 0;
@@ -322,7 +322,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
         }
         for (auto& l : cl)
             if (!l.segs.empty()) c->type_launches.push_back(std::move(l));
-        jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel};
+        jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel, false};
         // One wave per item = 64 consecutive blocks of one type and channel. The block lists are group-major (256 x 256 px
         // groups in raster order), so item k of every type covers about the same few groups. An 8 x 8 block's rows are 32-byte
         // pieces of 128-byte lines whose other pieces belong to blocks of other types: launched type after type, every line is
@@ -333,9 +333,13 @@ jxl_status finalize_tables(jxl_ctx* c) {
         struct Ord { uint32_t key; WorkItem w; };
         std::vector<Ord> ord;
         const int grs_c = std::max(1, (((channel < 0 ? c->bw : (c->bw >> c->sx[channel])) + 31) >> 5));
+        // frames without chroma subsampling: one item = 64 blocks with all three channels (k_idct_special_wg);
+        // per-channel launches: one item per channel (the lane-per-block kernel)
+        static const bool special_wg = !(getenv("JXL_SPECIAL_WG") && atoi(getenv("JXL_SPECIAL_WG")) == 0);
+        const bool wg_items = channel < 0 && special_wg;
         for (int t : kSpecial)
             for (uint32_t o = 0; o < lists[t].size(); o += 64)
-                for (uint32_t ch = ch0; ch < ch1; ch++) {
+                for (uint32_t ch = ch0; ch < (wg_items ? ch0 + 1 : ch1); ch++) {
                     const DevBlock& b0 = lists[t][o];
                     ord.push_back(Ord{(uint32_t)((b0.cy >> 5) * grs_c + (b0.cx >> 5)),
                                       WorkItem{(uint32_t)t | (ch << 8), first_of[t] + o, (uint32_t)std::min<size_t>(64, lists[t].size() - o)}});
@@ -343,7 +347,8 @@ jxl_status finalize_tables(jxl_ctx* c) {
         static const bool spatial = !(getenv("JXL_SPECIAL_SPATIAL") && atoi(getenv("JXL_SPECIAL_SPATIAL")) == 0);
         if (spatial && ord.size() > 8) {
             std::stable_sort(ord.begin(), ord.end(), [](const Ord& x, const Ord& y) { return x.key < y.key; });
-            static const int run = getenv("JXL_SPECIAL_RUN") ? std::max(1, atoi(getenv("JXL_SPECIAL_RUN"))) : 32;
+            static const int run_env = getenv("JXL_SPECIAL_RUN") ? std::max(1, atoi(getenv("JXL_SPECIAL_RUN"))) : 0;
+            const int run = run_env ? run_env : wg_items ? 12 : 32;  // about the items of the few groups one item spans
             std::vector<WorkItem> q[8];
             for (size_t i = 0; i < ord.size(); i++) q[(i / (size_t)run) % 8].push_back(ord[i].w);
             size_t longest = 0;
@@ -353,6 +358,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
         } else {
             for (const Ord& o : ord) items.push_back(o.w);
         }
+        sl.wg_items = wg_items;
         sl.n_items = (int)items.size() - sl.items_off;
         if (sl.n_items > 0) c->special_launches.push_back(sl);
     };
@@ -1121,7 +1127,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 (void)hipStreamWaitEvent(side, c->fork_ev, 0);
             }
             for (const auto& sl : c->special_launches) {
-                launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, side);
+                launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, side, sl.wg_items);
                 launches++;
             }
             if (any_llf) {
@@ -1175,7 +1181,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 launches++;
             }
             for (const auto& sl : c->special_launches) {
-                launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, pick());
+                launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, pick(), sl.wg_items);
                 launches++;
             }
             if (fork)
@@ -1304,6 +1310,8 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
 
 // frames whose IDCT stage can share launches: plain 4:4:4 frames made of the merged-launch types
 bool batchable(const jxl_ctx* c) {
+    for (const auto& sl : c->special_launches)
+        if (!sl.wg_items) return false;  // k_idct_special_batch takes workgroup items
     return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && (c->p.stages & JXL_STAGE_IDCT);
 }
 }  // namespace

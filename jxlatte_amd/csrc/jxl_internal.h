@@ -139,7 +139,7 @@ void launch_idct_multi_batch(const MultiArgs* dev_args, int n_frames, int grid_x
 void launch_idct_special_batch(const MultiArgs* dev_args, int n_frames, int max_items, hipStream_t s);
 // the special 8x8-footprint types: items of up to 64 blocks (one per lane)
 void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],
-                         hipStream_t s);
+                         hipStream_t s, bool wg_items);
 int medium_blocks_per_wg(int type);
 // finalizeLLF of blocks[first..first+count) (all larger than 8x8) into the llf planes
 void launch_llf(const DevFrame& f, const DevBlock* blocks, int first, int count, float* const llf[3], hipStream_t s);

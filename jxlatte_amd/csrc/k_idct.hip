@@ -1209,23 +1209,178 @@ __global__ __launch_bounds__(64) void k_idct_special(const DevFrame f, const Dev
     idct_special_body(f, blocks, items, o0, o1, o2);
 }
 
-// batch form: MultiArgs block per frame (f, blocks, items, o0..2; seg_n[0] = number of items)
-__global__ __launch_bounds__(64) void k_idct_special_batch(const MultiArgs* __restrict__ args) {
+// ---- the nine special 8x8 types, workgroup form (frames without chroma subsampling) -----------------------------------
+// The lane-per-block kernel above makes every lane fetch its own 8 (+ 8 luma) rows one dependent load after the other,
+// dequantises luma again for both chroma channels and divides once per sample: 20-27 us for a few hundred waves, the most
+// expensive kernel of a real 720p frame. Here a 256-thread workgroup takes 64 blocks of one type with all three channels:
+//   A. every lane fetches four 16-byte coefficient groups per channel -- all loads of the item are in flight at once --
+//      dequantises them through the 3 x 64 sign / bias / (a - qbn / a) table (HFCoefficients.java:309-315, as in
+//      k_idct_wg3), applies chroma-from-luma from the luma value it holds, and parks the block images in LDS;
+//   B. lane (channel, block) lifts its 64 samples out of LDS (row stride 65: bank = lane + i), runs the type's transform
+//      (invert_small: PassGroup.java:83-168, 234-325) in registers and puts the pixels back;
+//   C. the lanes of A write the pixels out, 16 bytes each.
+// Same operations per sample as the lane-per-block form, so the same bits.
+#define JXL_SPECIAL_WG_LDS ((192 * 65 + 192) * sizeof(float))
+__device__ __forceinline__ void special_wg_body(const DevFrame& f, const DevBlock* __restrict__ blocks, const WorkItem it, float* o0, float* o1,
+                                                float* o2) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    __shared__ float img[192 * 65];
+    __shared__ float qtab[192];
+    const int tid = threadIdx.x;
+    const int type = (int)(it.type & 0xffu), n = (int)it.count;
+    const float qbn = f.quant_bias_numerator;
+    if (tid < 192) {
+        const int c = tid >> 6, a = tid & 63;
+        qtab[tid] = a == 0 ? 0.0f : a == 1 ? f.quant_bias[c] : (float)a - qbn / (float)a;
+    }
+    const int PI = JXL_TT[type].param_index;
+    const float* wt[3] = {f.weights + f.woffs[PI * 3], f.weights + f.woffs[PI * 3 + 1], f.weights + f.woffs[PI * 3 + 2]};
+    const int W = f.width;
+    // ---- A: loads of the four groups of this lane
+    v4i_t q[4][3];
+    v4f_t wv[3];
+    int gx[4];
+    float hfm[4], kx[4], kb[4], lfv[4][3];
+    const int r = tid & 15, row = r >> 1, half = r & 1;  // the same (row, half) for all four groups: blocks tid/16 + 16 k
+#pragma unroll
+    for (int c = 0; c < 3; c++) wv[c] = *reinterpret_cast<const v4f_t*>(wt[c] + row * 8 + half * 4);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int blk = (tid >> 4) + 16 * k;
+        gx[k] = -1;
+        hfm[k] = 1.0f;
+        kx[k] = kb[k] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            q[k][c] = v4i_t{0, 0, 0, 0};
+            lfv[k][c] = 0.0f;
+        }
+        if (blk < n) {
+            const DevBlock b = load_block(blocks, (int)it.first + blk);
+            gx[k] = (int)b.cy | ((int)b.cx << 16);
+            hfm[k] = (float)b.hf_mul;
+            const int64_t off = (int64_t)(b.cy * 8 + row) * W + b.cx * 8 + half * 4;
+#pragma unroll
+            for (int c = 0; c < 3; c++) q[k][c] = *reinterpret_cast<const v4i_t*>(f.coeff[c] + off);
+            cfl_factors(f, (b.cy * 8) >> 6, (b.cx * 8) >> 6, b.cfl_zero & 1u, kx[k], kb[k]);
+            if (r == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) lfv[k][c] = f.lf[c][(int64_t)b.cy * f.bw + b.cx];
+            }
+        }
+    }
+    __syncthreads();  // qtab
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int blk = (tid >> 4) + 16 * k;
+        if (gx[k] < 0) continue;
+        const float sf[3] = {f.scale_factor[0] / hfm[k], f.scale_factor[1] / hfm[k], f.scale_factor[2] / hfm[k]};
+        float dq[3][4];
+        int big = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int qv = q[k][c][i];
+                const int aq = qv < 0 ? -qv : qv;
+                big |= aq;
+                const float m = qtab[c * 64 + (aq & 63)];
+                dq[c][i] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, m) ^ ((uint32_t)qv & 0x80000000u));
+            }
+        if ((uint32_t)big >= 64u) {
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int qv = q[k][c][i];
+                    const int aq = qv < 0 ? -qv : qv;
+                    if (aq >= 64) dq[c][i] = (float)qv - qbn / (float)qv;
+                }
+        }
+        float* d0 = img + (0 * 64 + blk) * 65 + row * 8 + half * 4;
+        float* d1 = img + (1 * 64 + blk) * 65 + row * 8 + half * 4;
+        float* d2 = img + (2 * 64 + blk) * 65 + row * 8 + half * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float dy = dq[1][i] * sf[1] * wv[1][i];
+            float dx = dq[0][i] * sf[0] * wv[0][i] + kx[k] * dy;  // chromaFromLuma (HFCoefficients.java:186-188)
+            float db = dq[2][i] * sf[2] * wv[2][i] + kb[k] * dy;
+            float yy = dy;
+            if (r == 0 && i == 0) {  // finalizeLLF of a 1x1 dctSelect: the LF sample itself (see small_row)
+                dx = lfv[k][0];
+                yy = lfv[k][1];
+                db = lfv[k][2];
+            }
+            d0[i] = dx;
+            d1[i] = yy;
+            d2[i] = db;
+        }
+    }
+    __syncthreads();
+    // ---- B: one lane per (channel, block)
+    if (tid < 192 && (tid & 63) < n) {
+        float co[64], px[64];
+        float* im = img + tid * 65;
+#pragma unroll
+        for (int i = 0; i < 64; i++) co[i] = im[i];
+        switch (type) {
+        case 1: invert_small<1>(co, px); break;
+        case 2: invert_small<2>(co, px); break;
+        case 3: invert_small<3>(co, px); break;
+        case 12: invert_small<12>(co, px); break;
+        case 13: invert_small<13>(co, px); break;
+        case 14: invert_small<14>(co, px); break;
+        case 15: invert_small<15>(co, px); break;
+        case 16: invert_small<16>(co, px); break;
+        case 17: invert_small<17>(co, px); break;
+        default: break;
+        }
+#pragma unroll
+        for (int i = 0; i < 64; i++) im[i] = px[i];
+    }
+    __syncthreads();
+    // ---- C: pixels out
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (gx[k] < 0) continue;
+        const int blk = (tid >> 4) + 16 * k;
+        const int cy = gx[k] & 0xffff, cx = (int)((uint32_t)gx[k] >> 16);
+        const int64_t off = (int64_t)(cy * 8 + row) * W + cx * 8 + half * 4;
+        float* o3[3] = {o0, o1, o2};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float* sp = img + (c * 64 + blk) * 65 + row * 8 + half * 4;
+            *reinterpret_cast<v4f_t*>(o3[c] + off) = v4f_t{sp[0], sp[1], sp[2], sp[3]};
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_idct_special_wg(const DevFrame f, const DevBlock* __restrict__ blocks,
+                                                         const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+    special_wg_body(f, blocks, items[blockIdx.x], o0, o1, o2);
+}
+
+// batch form: MultiArgs block per frame (f, blocks, items, o0..2; seg_n[0] = number of items); items in the workgroup form
+__global__ __launch_bounds__(256) void k_idct_special_batch(const MultiArgs* __restrict__ args) {
     typedef const __attribute__((address_space(4))) MultiArgs* cargs;
     const MultiArgs& a = *(const MultiArgs*)((cargs)args + blockIdx.y);
     if ((int)blockIdx.x >= a.seg_n[0]) return;
-    idct_special_body(a.f, a.blocks, a.items, a.o0, a.o1, a.o2);
+    special_wg_body(a.f, a.blocks, a.items[blockIdx.x], a.o0, a.o1, a.o2);
 }
 
 void launch_idct_special_batch(const MultiArgs* dev_args, int n_frames, int max_items, hipStream_t s) {
     if (n_frames <= 0 || max_items <= 0) return;
-    hipLaunchKernelGGL(k_idct_special_batch, dim3(max_items, n_frames), dim3(64), 0, s, dev_args);
+    hipLaunchKernelGGL(k_idct_special_batch, dim3(max_items, n_frames), dim3(256), 0, s, dev_args);
 }
 
+// wg_items: items name 64 blocks of all three channels (k_idct_special_wg); else one channel each (the lane-per-block kernel:
+// chroma-subsampled frames, whose channels have their own geometry and no chroma-from-luma)
 void launch_idct_special(const DevFrame& f, const DevBlock* blocks, const WorkItem* items, int n_items, float* const out[3],
-                         hipStream_t s) {
+                         hipStream_t s, bool wg_items) {
     if (n_items <= 0) return;
-    hipLaunchKernelGGL(k_idct_special, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
+    if (wg_items) hipLaunchKernelGGL(k_idct_special_wg, dim3(n_items), dim3(256), 0, s, f, blocks, items, out[0], out[1], out[2]);
+    else hipLaunchKernelGGL(k_idct_special, dim3(n_items), dim3(64), 0, s, f, blocks, items, out[0], out[1], out[2]);
 }
 
 
