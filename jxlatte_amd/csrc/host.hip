@@ -2245,6 +2245,10 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
             if (op.rdim > squeeze_seg(sd) && !getenv("JXL_SQUEEZE_SERIAL")) {  // segmented walk: chain state per segment start
                 sd.side = alloc((size_t)((op.rdim + squeeze_seg(sd) - 1) / squeeze_seg(sd)) * op.other);
                 if (!sd.side) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze segment states)");
+                if (!getenv("JXL_SQUEEZE_NO_TAIL")) {
+                    sd.tail = alloc((size_t)((op.rdim + squeeze_seg(sd) - 1) / squeeze_seg(sd)) * op.other);
+                    if (!sd.tail) return fail(c, JXL_ERR_OOM, "device allocation failed (squeeze segment states)");
+                }
             }
             batch.bt.d[batch.bt.n++] = sd;
             if (batch.bt.n == 8) {
@@ -2288,7 +2292,7 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
             std::vector<SqueezeBatch> steps;
             for (size_t q = 0; q < run; q++) {
                 SqueezeBatch bt = c->mod_ops[q].bt;
-                for (int i = 0; i < bt.n; i++) bt.d[i].side = nullptr;  // full serial walks: no segment states
+                for (int i = 0; i < bt.n; i++) bt.d[i].side = bt.d[i].tail = nullptr;  // full serial walks: no segment states
                 steps.push_back(bt);
             }
             c->mod_bufs.emplace_back();

@@ -202,6 +202,8 @@ struct SqueezeDesc {
     int other;         // the other dimension (rows for H, columns for V)
     int32_t* side;     // [nseg][other] chain state at every segment start (segmented mode), or null: one segment
     int seg, warm;     // pairs per segment and warm-up pairs in front of it (multiples of 8); 0: kSqueezeSeg / kSqueezeWarm
+    int32_t* tail;     // [nseg][other] last output of every segment but the last (what side[s + 1] is checked against), or null:
+                       // the check reads it from the output plane (for H steps that is one cache line per row and segment)
 };
 __host__ __device__ inline int squeeze_seg(const SqueezeDesc& d);
 __host__ __device__ inline int squeeze_warm(const SqueezeDesc& d);

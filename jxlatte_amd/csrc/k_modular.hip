@@ -249,6 +249,7 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
             }
         }
     }
+    if (d.tail && s + 1 < nseg) d.tail[(int64_t)s * w + x] = top;  // last output of this segment: what segment s + 1 is checked against
     if (s == 0 && ah > rh) out[(int64_t)(2 * rh) * ok] = avg[(int64_t)rh * ak];
 }
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void k_squeeze_verify(const SqueezeBatch bt) {
     auto po = [&](int k) { return hz ? out + (int64_t)i * ow + k : out + (int64_t)k * n + i; };
     int bad = 0;
     for (int s = nseg - 1; s >= 1; s--)
-        if (d.side[(int64_t)s * n + i] != *po(2 * s * squeeze_seg(d) - 1)) bad = s;
+        if (d.side[(int64_t)s * n + i] != (d.tail ? d.tail[(int64_t)(s - 1) * n + i] : *po(2 * s * squeeze_seg(d) - 1))) bad = s;
     if (__builtin_expect(bad == 0, 1)) return;
     if (bt.flag) {  // report only: the following steps have already consumed this step's output
         atomicOr(bt.flag, 1);
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
         }
         x0 += cols;
     }
+    if (d.tail && s + 1 < nseg && lane < rows) d.tail[(int64_t)s * h + y0 + lane] = left;  // last output of this segment
     if (s == 0 && aw > rw && lane < rows) out[(int64_t)(y0 + lane) * ow + 2 * rw] = avg[(int64_t)(y0 + lane) * aw + rw];
 }
 
