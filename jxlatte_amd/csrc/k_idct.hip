@@ -1410,12 +1410,16 @@ __global__ __launch_bounds__(256) void k_large_dequant(const DevFrame f, const D
     }
 }
 
-// phase B: column pass. unit = (block, channel, 64-column strip, 64-output chunk); one wave per unit.
-// src/dst are frame planes; lane = column. dst[k][x] = idct over n of src[n][x].
+// phase B: column pass. unit = (block, channel, 64-column strip, output chunk); one wave per unit, lane = column.
+// dst[k][x] = idct over n of src[n][x]. A unit produces the 32 outputs [32 chunk, 32 chunk + 32) and their 32 mirror images
+// (MirrorAcc: every product src[n] * lut[n-1][k] serves outputs k and N-1-k), so a table row costs 32 scalar registers instead
+// of 64 -- room for the next row to be in flight while this one is used -- and 96 instead of 128 operations per input sample.
+// The table goes through the constant address space: as plain global memory the 64 table values of a step were fetched by
+// every lane (r1: 215 us for the default large mix's column passes).
 __global__ __launch_bounds__(64) void k_large_colpass(const DevFrame f, const DevBlock* __restrict__ blocks, int first,
                                                       const float* s0p, const float* s1p, const float* s2p, float* d0, float* d1,
                                                       float* d2) {
-    const DevBlock b = blocks[first + blockIdx.z];
+    const DevBlock b = load_block(blocks, first + (int)blockIdx.z);
     const jxl_tt_info tt = JXL_TT[b.type];
     const int H = tt.ph, W = tt.pw;
     const int c = blockIdx.y;
@@ -1427,28 +1431,33 @@ __global__ __launch_bounds__(64) void k_large_colpass(const DevFrame f, const De
     float* dst = c == 0 ? d0 : c == 1 ? d1 : d2;
     const int FW = f.width;
     const int64_t base = (int64_t)(b.cy * 8) * FW + b.cx * 8 + strip * 64 + threadIdx.x;
-    const float* lut = f.lut + lut_off(ceil_log2_dev(H)) + chunk * 64;
-    float acc[64];
-    const float s0 = src[base];
-#pragma unroll
-    for (int k = 0; k < 64; k++) acc[k] = s0;
-    for (int n = 1; n < H; n++) {
-        const float s2 = src[base + (int64_t)n * FW];
-        const float* lr = lut + (n - 1) * H;
-#pragma unroll
-        for (int k = 0; k < 64; k++) acc[k] = acc[k] + s2 * lr[k];
+    const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(H)) + chunk * 32);
+    MirrorAcc<64> acc;
+    acc.init(src[base]);
+    // (odd, even) pairs of steps; H is even, so the last odd n stands alone
+    float s1 = src[base + FW], s2 = src[base + 2 * (int64_t)FW];
+    for (int n = 1; n < H; n += 2) {
+        const float c1 = s1, c2 = s2;
+        if (n + 2 < H) s1 = src[base + (int64_t)(n + 2) * FW];
+        if (n + 3 < H) s2 = src[base + (int64_t)(n + 3) * FW];
+        acc.template step<true>(c1, lut + (n - 1) * H);
+        if (n + 1 < H) acc.template step<false>(c2, lut + n * H);
     }
 #pragma unroll
-    for (int k = 0; k < 64; k++) dst[base + (int64_t)(chunk * 64 + k) * FW] = acc[k];
+    for (int i = 0; i < 32; i++) {
+        dst[base + (int64_t)(chunk * 32 + i) * FW] = acc.get(i);
+        dst[base + (int64_t)(H - 1 - chunk * 32 - i) * FW] = acc.get(63 - i);
+    }
 }
 
-// phase C: row pass. unit = (block, channel, 64-row strip, 64-output chunk); lane = row, tiles staged
-// through LDS so that global loads and stores stay row-contiguous.
+// phase C: row pass. unit = (block, channel, 64-row strip, output chunk); lane = row, 64 x 64 tiles of the input staged through
+// LDS so that global loads and stores stay row-contiguous; the outputs of a unit are the columns [32 chunk, 32 chunk + 32) and
+// their mirror images [W - 32 chunk - 32, W - 32 chunk): two 128-byte runs per row.
 __global__ __launch_bounds__(64) void k_large_rowpass(const DevFrame f, const DevBlock* __restrict__ blocks, int first,
                                                       const float* s0p, const float* s1p, const float* s2p, float* d0, float* d1,
                                                       float* d2) {
     __shared__ float tile[64 * 65];
-    const DevBlock b = blocks[first + blockIdx.z];
+    const DevBlock b = load_block(blocks, first + (int)blockIdx.z);
     const jxl_tt_info tt = JXL_TT[b.type];
     const int H = tt.ph, W = tt.pw;
     const int c = blockIdx.y;
@@ -1461,30 +1470,31 @@ __global__ __launch_bounds__(64) void k_large_rowpass(const DevFrame f, const De
     const int FW = f.width;
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)(b.cy * 8 + strip * 64) * FW + b.cx * 8;
-    const float* lut = f.lut + lut_off(ceil_log2_dev(W)) + chunk * 64;
-    float acc[64];
+    const cfloatp lut = as_const(f.lut + lut_off(ceil_log2_dev(W)) + chunk * 32);
+    MirrorAcc<64> acc;
     for (int n0 = 0; n0 < W; n0 += 64) {
         __syncthreads();
-        for (int r = 0; r < 64; r++) tile[r * 65 + lane] = src[base + (int64_t)r * FW + n0 + lane];
+        float t[64];
+#pragma unroll
+        for (int r = 0; r < 64; r++) t[r] = src[base + (int64_t)r * FW + n0 + lane];  // all 64 row loads of the tile in flight
+#pragma unroll
+        for (int r = 0; r < 64; r++) tile[r * 65 + lane] = t[r];
         __syncthreads();
-        for (int nn = 0; nn < 64; nn++) {
+        const float* row = tile + lane * 65;
+        if (n0 == 0) acc.init(row[0]);
+        // n = n0 + nn: nn and n have the same parity (n0 is a multiple of 64)
+        for (int nn = n0 == 0 ? 1 : 0; nn < 64; nn++) {
             const int n = n0 + nn;
-            const float s2 = tile[lane * 65 + nn];
-            if (n == 0) {
-#pragma unroll
-                for (int k = 0; k < 64; k++) acc[k] = s2;
-            } else {
-                const float* lr = lut + (n - 1) * W;
-#pragma unroll
-                for (int k = 0; k < 64; k++) acc[k] = acc[k] + s2 * lr[k];
-            }
+            if (nn & 1) acc.template step<true>(row[nn], lut + (n - 1) * W);
+            else acc.template step<false>(row[nn], lut + (n - 1) * W);
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 64; k++) tile[lane * 65 + k] = acc[k];
+    for (int i = 0; i < 64; i++) tile[lane * 65 + i] = acc.get(i);  // i < 32: column 32 chunk + i; i >= 32: W - 32 chunk - 64 + i
     __syncthreads();
-    for (int r = 0; r < 64; r++) dst[base + (int64_t)r * FW + chunk * 64 + lane] = tile[r * 65 + lane];
+    const int col = lane < 32 ? chunk * 32 + lane : W - 32 * chunk - 64 + lane;
+    for (int r = 0; r < 64; r++) dst[base + (int64_t)r * FW + col] = tile[r * 65 + lane];
 }
 
 void launch_idct_large(const DevFrame& f, const DevBlock* blocks, const DevBlock* host_blocks, int first, int count,
