@@ -1419,12 +1419,15 @@ __global__ __launch_bounds__(256) void k_large_dequant(const DevFrame f, const D
 __global__ __launch_bounds__(64) void k_large_colpass(const DevFrame f, const DevBlock* __restrict__ blocks, int first,
                                                       const float* s0p, const float* s1p, const float* s2p, float* d0, float* d1,
                                                       float* d2) {
-    const DevBlock b = load_block(blocks, first + (int)blockIdx.z);
+    // grid = (block, channel, unit): the units a block does not have (4 of 16 for 128 x 128) are the LAST workgroups of the launch.
+    // With the unit in x, those empty workgroups sat at fixed residues of the linear id, and the workgroups with work all
+    // landed on half of the XCDs (id % 8): a 128 x 128 frame took 1.6x the time of a 256 x 256 one
+    const DevBlock b = load_block(blocks, first + (int)blockIdx.x);
     const jxl_tt_info tt = JXL_TT[b.type];
     const int H = tt.ph, W = tt.pw;
     const int c = blockIdx.y;
     const int strips = W / 64, chunks = H / 64;
-    const int u = blockIdx.x;
+    const int u = blockIdx.z;
     if (u >= strips * chunks) return;
     const int strip = u % strips, chunk = u / strips;
     const float* src = c == 0 ? s0p : c == 1 ? s1p : s2p;
@@ -1457,12 +1460,12 @@ __global__ __launch_bounds__(64) void k_large_rowpass(const DevFrame f, const De
                                                       const float* s0p, const float* s1p, const float* s2p, float* d0, float* d1,
                                                       float* d2) {
     __shared__ float tile[64 * 65];
-    const DevBlock b = load_block(blocks, first + (int)blockIdx.z);
+    const DevBlock b = load_block(blocks, first + (int)blockIdx.x);
     const jxl_tt_info tt = JXL_TT[b.type];
     const int H = tt.ph, W = tt.pw;
     const int c = blockIdx.y;
     const int strips = H / 64, chunks = W / 64;
-    const int u = blockIdx.x;
+    const int u = blockIdx.z;
     if (u >= strips * chunks) return;
     const int strip = u % strips, chunk = u / strips;
     const float* src = c == 0 ? s0p : c == 1 ? s1p : s2p;
@@ -1504,9 +1507,9 @@ void launch_idct_large(const DevFrame& f, const DevBlock* blocks, const DevBlock
     // every large type has <= 256x256 samples: 32 workgroups of 256 threads x 8 samples
     hipLaunchKernelGGL(k_large_dequant, dim3(32, count), dim3(256), 0, s, f, blocks, first, out[0], out[1], out[2]);
     // at most (256/64)*(256/64) = 16 units per (block, channel)
-    hipLaunchKernelGGL(k_large_colpass, dim3(16, 3, count), dim3(64), 0, s, f, blocks, first, out[0], out[1], out[2],
+    hipLaunchKernelGGL(k_large_colpass, dim3(count, 3, 16), dim3(64), 0, s, f, blocks, first, out[0], out[1], out[2],
                        scratch[0], scratch[1], scratch[2]);
-    hipLaunchKernelGGL(k_large_rowpass, dim3(16, 3, count), dim3(64), 0, s, f, blocks, first, scratch[0], scratch[1],
+    hipLaunchKernelGGL(k_large_rowpass, dim3(count, 3, 16), dim3(64), 0, s, f, blocks, first, scratch[0], scratch[1],
                        scratch[2], out[0], out[1], out[2]);
     if (n_launches) *n_launches += 3;
 }
