@@ -1393,8 +1393,9 @@ __global__ __launch_bounds__(256) void k_large_dequant(const DevFrame f, const D
     BlockCtx k;
     make_block_ctx(f, b, tt.ph, tt.pw, tt.param_index, k);
     const int n = tt.ph * tt.pw;
+    const int lw = __builtin_ctz((unsigned)tt.pw);  // block edges are powers of two
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int y = i / tt.pw, x = i % tt.pw;
+        const int y = i >> lw, x = i & (tt.pw - 1);
         float dq[3];
         dequant_sample(f, k, y, x, dq);
         if (y < k.dsh && x < k.dsw) {  // finalizeLLF result (k_llf)
