@@ -182,8 +182,14 @@ struct FusedArgs {
     const int32_t* hf_mul;
     const int32_t* sharpness;
     int W, H, bw;
+    int ring_only;         // tile kernel: only the tiles that touch the frame-edge ring (the interior is k_restore_stream's)
+    int ring_tx, ring_ty;  // first tile column / row of the right / bottom border (filled by the launcher)
     RestoreParams p;
 };
+// k_restore_stream.hip: the interior of a frame (every pixel at least restore_stream_ring() away from the frame edges)
+int restore_stream_ring(const RestoreParams& p);
+bool restore_stream_covers(const FusedArgs& a);
+void launch_restore_stream(const FusedArgs& a, hipStream_t s);
 // false if the configuration is not covered by the fused kernel
 bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                              const int32_t* sharpness, const RestoreParams& p, FusedArgs& a);

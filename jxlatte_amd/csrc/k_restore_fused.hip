@@ -22,7 +22,7 @@
 // edge tiles re-create that by copying mirrored positions inside LDS after each stage.
 #include "jxl_internal.h"
 #include <algorithm>
-#include "jxl_fastpow.h"
+#include "restore_sink.h"
 #include <cstdlib>
 
 namespace jxl {
@@ -57,29 +57,6 @@ struct Geo {
     static constexpr int PLANE = SW * SH;
     static constexpr size_t LDS_BYTES = sizeof(float) * (3 * PLANE + 16 * 16);
 };
-
-// Java (int)float
-__device__ __forceinline__ int32_t f2i_java(float v) {
-    if (v != v) return 0;
-    if (v >= 2147483648.0f) return INT32_MAX;
-    if (v <= -2147483648.0f) return INT32_MIN;
-    return (int32_t)v;
-}
-// PQ / sRGB through jxl_fastpow.h (~110 instead of 463 instructions for the PQ curve, float results identical on all
-// sampled inputs; JXL_EXACT_POW builds the ocml pow() form for comparison)
-#ifdef JXL_EXACT_POW
-__device__ __forceinline__ float tf_pq_f(float f) {
-    const double d = pow((double)f, 0.159423828125);
-    return (float)pow((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375);
-}
-__device__ __forceinline__ float tf_srgb_f(float f) {
-    if (f < 0.00313066844250063f) return f * 12.92f;
-    return 1.055f * (float)pow((double)f, 0.4166666666666667) + -0.055f;
-}
-#else
-__device__ __forceinline__ float tf_pq_f(float f) { return fp_tf_pq(f); }
-__device__ __forceinline__ float tf_srgb_f(float f) { return fp_tf_srgb(f); }
-#endif
 
 // canonical |P[u] - P[v]| * s: operands ordered by index so equal terms are literally the same expression
 template <int PS>
@@ -388,49 +365,9 @@ struct OutSink {
     const FusedArgs& a;
     const TileCtx& tc;
     __device__ __forceinline__ void colour(float& v0, float& v1, float& v2) const {
-        if (a.p.xyb) {
-            const XybParams& xp = a.p.xybp;
-            const float gammaL = v1 + v0 + xp.cob[0];
-            const float gammaM = v1 - v0 + xp.cob[1];
-            const float gammaS = v2 + xp.cob[2];
-            const float mixL = (gammaL * gammaL) * gammaL + xp.ob[0];
-            const float mixM = (gammaM * gammaM) * gammaM + xp.ob[1];
-            const float mixS = (gammaS * gammaS) * gammaS + xp.ob[2];
-            v0 = xp.sm[0] * mixL + xp.sm[1] * mixM + xp.sm[2] * mixS;
-            v1 = xp.sm[3] * mixL + xp.sm[4] * mixM + xp.sm[5] * mixS;
-            v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
-        }
+        if (a.p.xyb) sink_colour(a.p.xybp, v0, v1, v2);
     }
-    __device__ __forceinline__ void store1(uint32_t g, float v0, float v1, float v2) const {
-        float v[3] = {v0, v1, v2};
-        if (PLAIN) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
-            return;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float t = v[c];
-#ifndef JXL_EXACT_POW
-            if (a.p.transfer == JXL_TRANSFER_PQ && a.p.pq_tab) t = fp_tf_pq_tab(t, reinterpret_cast<const float4*>(a.p.pq_tab));
-            else
-#endif
-            if (a.p.transfer == JXL_TRANSFER_PQ) t = tf_pq_f(t);
-            else if (a.p.transfer == JXL_TRANSFER_SRGB) t = tf_srgb_f(t);
-            if (a.p.max_value > 0) {
-                int32_t q = f2i_java(t * (float)a.p.max_value + 0.5f);
-                q = q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
-                if (a.p.interleaved) {  // R,G,B per pixel in out[0] (PNGWriter.writeIDAT order)
-                    if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
-                    else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
-                } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
-                else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
-                else ((int32_t*)a.out[c])[g] = q;
-            } else {
-                ((float*)a.out[c])[g] = t;
-            }
-        }
-    }
+    __device__ __forceinline__ void store1(uint32_t g, float v0, float v1, float v2) const { sink_store<PLAIN>(a, g, v0, v1, v2); }
     // one pixel at region position (y, x)
     __device__ __forceinline__ void operator()(int y, int x, float v0, float v1, float v2) const {
         const int gy = tc.iy0 + y, gx = tc.ix0 + x;
@@ -487,11 +424,35 @@ __device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
     // XCD one contiguous run of tiles in raster order: neighbouring tiles (shared halo reads, shared 128-byte
     // lines of the 62-wide output rows) then meet in the same L2. Speed only, never correctness.
     const int tiles_x = (W + G::OW - 1) / G::OW, tiles_y = (H + G::OH - 1) / G::OH;
-    const int n_tiles = tiles_x * tiles_y;
-    const int per_xcd = (n_tiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-    if (tile >= n_tiles) return;  // uniform per workgroup, before any barrier
-    const int ox = (tile % tiles_x) * G::OW, oy = (tile / tiles_x) * G::OH;
+    int ox, oy;
+    if (a.ring_only) {
+        // only the tiles that hold pixels of the frame-edge ring (the interior belongs to k_restore_stream): every tile of the
+        // top / bottom border rows, then the left / right border tiles of the rows between (see ring_tile_count)
+        const int nTB = a.ring_ty > 0 ? 1 + tiles_y - a.ring_ty : tiles_y;
+        const int nLR = a.ring_tx > 0 ? 1 + tiles_x - a.ring_tx : tiles_x;
+        const int idx = (int)blockIdx.x;
+        int tx, ty;
+        if (idx < tiles_x * nTB) {
+            const int j = idx / tiles_x;
+            tx = idx - j * tiles_x;
+            ty = a.ring_ty > 0 ? (j == 0 ? 0 : a.ring_ty + j - 1) : j;
+        } else {
+            const int i2 = idx - tiles_x * nTB;
+            const int row = i2 / nLR, k = i2 - row * nLR;
+            ty = row + 1;
+            tx = a.ring_tx > 0 ? (k == 0 ? 0 : a.ring_tx + k - 1) : k;
+            if (ty >= a.ring_ty) return;  // uniform per workgroup, before any barrier
+        }
+        ox = tx * G::OW;
+        oy = ty * G::OH;
+    } else {
+        const int n_tiles = tiles_x * tiles_y;
+        const int per_xcd = (n_tiles + 7) >> 3;
+        const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+        if (tile >= n_tiles) return;  // uniform per workgroup, before any barrier
+        ox = (tile % tiles_x) * G::OW;
+        oy = (tile / tiles_x) * G::OH;
+    }
     tc.ix0 = ox - G::RT;
     tc.iy0 = oy - G::RT;
     tc.edge = tc.ix0 < 0 || tc.iy0 < 0 || tc.ix0 + G::IW > W || tc.iy0 + G::IH > H;
@@ -672,7 +633,20 @@ void launch_tph(const FusedArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_BYTES + pad));
         attr_set = true;
     }
-    const int n_tiles = ((a.W + G::OW - 1) / G::OW) * ((a.H + G::OH - 1) / G::OH);
+    const int tiles_x = (a.W + G::OW - 1) / G::OW, tiles_y = (a.H + G::OH - 1) / G::OH;
+    if (a.ring_only) {
+        // tiles that intersect the ring of G::RT pixels along the frame edges
+        FusedArgs r = a;
+        r.ring_tx = (a.W - G::RT) / G::OW;
+        r.ring_ty = (a.H - G::RT) / G::OH;
+        const int nTB = r.ring_ty > 0 ? 1 + tiles_y - r.ring_ty : tiles_y;
+        const int nLR = r.ring_tx > 0 ? 1 + tiles_x - r.ring_tx : tiles_x;
+        const int mid = r.ring_ty > 0 ? r.ring_ty - 1 : 0;
+        const dim3 grid(tiles_x * nTB + mid * nLR);
+        hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, r);
+        return;
+    }
+    const int n_tiles = tiles_x * tiles_y;
     const dim3 grid(((n_tiles + 7) / 8) * 8);
     hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, a);
 }
@@ -707,6 +681,8 @@ bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h
     a.W = w;
     a.H = h;
     a.bw = (w + 7) >> 3;
+    a.ring_only = 0;
+    a.ring_tx = a.ring_ty = 0;
     a.p = p;
     return true;
 }
@@ -763,6 +739,11 @@ bool launch_restore_fused(const float* const in[3], void* const out[3], int h, i
                           const int32_t* sharpness, const RestoreParams& p, hipStream_t s) {
     FusedArgs a;
     if (!fill_restore_fused_args(in, out, h, w, hf_mul, sharpness, p, a)) return false;
+    if (restore_stream_covers(a)) {
+        // interior: register-streaming kernel (k_restore_stream.hip); the ring along the frame edges: this file's tiles
+        launch_restore_stream(a, s);
+        a.ring_only = 1;
+    }
     const int it = p.epf_iters;
     if (p.gab) {
         if (it == 0) launch_t<true, 0>(a, s);

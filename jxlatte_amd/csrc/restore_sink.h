@@ -1,0 +1,79 @@
+// Output sink shared by the fused restoration kernels (k_restore_fused.hip: LDS tiles, k_restore_stream.hip: register
+// streaming): OpsinInverseMatrix.invertXYB (OpsinInverseMatrix.java:105-142) + JXLImage.transferInPlace
+// (JXLImage.java:244-258, TransferFunction.java:39-44,83-87) + ImageBuffer.castToInt0 (ImageBuffer.java:129-147) + the
+// global store of one pixel.
+#pragma once
+#include "jxl_internal.h"
+#include "jxl_fastpow.h"
+
+namespace jxl {
+
+// Java (int)float
+__device__ __forceinline__ int32_t sink_f2i_java(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+// PQ / sRGB through jxl_fastpow.h (JXL_EXACT_POW builds the ocml pow() form for comparison)
+#ifdef JXL_EXACT_POW
+__device__ __forceinline__ float sink_tf_pq(float f) {
+    const double d = pow((double)f, 0.159423828125);
+    return (float)pow((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375);
+}
+__device__ __forceinline__ float sink_tf_srgb(float f) {
+    if (f < 0.00313066844250063f) return f * 12.92f;
+    return 1.055f * (float)pow((double)f, 0.4166666666666667) + -0.055f;
+}
+#else
+__device__ __forceinline__ float sink_tf_pq(float f) { return fp_tf_pq(f); }
+__device__ __forceinline__ float sink_tf_srgb(float f) { return fp_tf_srgb(f); }
+#endif
+
+// OpsinInverseMatrix.invertXYB of one pixel
+__device__ __forceinline__ void sink_colour(const XybParams& xp, float& v0, float& v1, float& v2) {
+    const float gammaL = v1 + v0 + xp.cob[0];
+    const float gammaM = v1 - v0 + xp.cob[1];
+    const float gammaS = v2 + xp.cob[2];
+    const float mixL = (gammaL * gammaL) * gammaL + xp.ob[0];
+    const float mixM = (gammaM * gammaM) * gammaM + xp.ob[1];
+    const float mixS = (gammaS * gammaS) * gammaS + xp.ob[2];
+    v0 = xp.sm[0] * mixL + xp.sm[1] * mixM + xp.sm[2] * mixS;
+    v1 = xp.sm[3] * mixL + xp.sm[4] * mixM + xp.sm[5] * mixS;
+    v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
+}
+
+// pixel g (= y * W + x) of the frame; PLAIN: float planes, no transfer function
+template <bool PLAIN>
+__device__ __forceinline__ void sink_store(const FusedArgs& a, uint32_t g, float v0, float v1, float v2) {
+    float v[3] = {v0, v1, v2};
+    if (PLAIN) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float t = v[c];
+#ifndef JXL_EXACT_POW
+        if (a.p.transfer == JXL_TRANSFER_PQ && a.p.pq_tab) t = fp_tf_pq_tab(t, reinterpret_cast<const float4*>(a.p.pq_tab));
+        else
+#endif
+        if (a.p.transfer == JXL_TRANSFER_PQ) t = sink_tf_pq(t);
+        else if (a.p.transfer == JXL_TRANSFER_SRGB) t = sink_tf_srgb(t);
+        if (a.p.max_value > 0) {
+            int32_t q = sink_f2i_java(t * (float)a.p.max_value + 0.5f);
+            q = q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
+            if (a.p.interleaved) {  // R,G,B per pixel in out[0] (PNGWriter.writeIDAT order)
+                if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
+                else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
+            } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+            else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
+            else ((int32_t*)a.out[c])[g] = q;
+        } else {
+            ((float*)a.out[c])[g] = t;
+        }
+    }
+}
+
+}  // namespace jxl

@@ -889,7 +889,9 @@ class JXLDecoder:
             rp = None
             resident = getattr(be, "resident", False) and colors == 3  # row f4: the stages after decodeFrame chained on the device
             if fr.encoding == VARDCT:
-                fuse_xyb = bool(info.xyb_encoded) and simple
+                # an LF frame's buffers are read back as XYB LF coefficients (LFCoefficients.java:44-57) and are stored
+                # BEFORE performColorTransforms (JXLCodestreamDecoder.java:615-617): never fuse the inverse XYB into them
+                fuse_xyb = bool(info.xyb_encoded) and simple and fr.lf_level == 0 and fr.type != LF_FRAME
                 # frames with stages between decodeFrame and the colour transform keep their colour planes on the device
                 # through those stages (row f4); LF frames / lfBuffer consumers need the padded planes on the host
                 if not simple and resident and fr.lf_level == 0 and fr.type != LF_FRAME:
