@@ -125,6 +125,9 @@ struct jxl_ctx {
     int32_t h_woffs_in[51] = {};
     DevBuf wg3_items[2];       // spatially ordered item lists of the two k_idct_wg3 classes (wg3_item_table)
     int wg3_item_count[2] = {0, 0};
+    std::vector<IdctSegment> wave_segs;  // the types k_idct_wave handles (frames without chroma subsampling)
+    DevBuf wave_items[2];                // their item lists by launch class (wave_item_table)
+    int wave_item_count[2] = {0, 0};
     std::vector<BatchLaunch> batch_launches;
     hipEvent_t batch_ev = nullptr;
     bool timing = false;
@@ -138,6 +141,8 @@ struct jxl_ctx {
     int n_aux = 1;  // side streams in use (JXL_AUX_STREAMS overrides). 1 is the batch-throughput optimum; 3 gives the lowest single-frame latency
     hipStream_t aux[kAux] = {};
     hipEvent_t fork_ev = nullptr, llf_ev = nullptr, join_ev[kAux] = {};
+    hipStream_t wave_side[2] = {nullptr, nullptr};  // k_idct_wave's own side streams (it waits for nothing but the frame's inputs)
+    hipEvent_t wave_fork_ev = nullptr, wave_join_ev[2] = {nullptr, nullptr};
 
     // ---- Modular state
     std::vector<DevBuf> mod_bufs;
@@ -297,6 +302,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     std::vector<WorkItem> items;
     c->type_launches.clear();
     c->special_launches.clear();
+    c->wave_segs.clear();
     static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
     auto lay_out = [&](const std::vector<DevBlock>* lists, int channel) {
@@ -316,6 +322,10 @@ jxl_status finalize_tables(jxl_ctx* c) {
         for (int t : kOrder) {
             if (lists[t].empty()) continue;
             const IdctSegment sg{t, (int)first_of[t], (int)lists[t].size()};
+            if (channel < 0 && wave_handles(t)) {  // k_idct_wave.hip: one wave per item, LLF inside the item
+                c->wave_segs.push_back(sg);
+                continue;
+            }
             const int cls = (use_wg3 && channel < 0 && wg3_handles(t)) ? (wg3_big(t) ? 3 : 2) : idct_class_of(t);
             for (auto& l : cl)
                 if (l.cls == cls) l.segs.push_back(sg);
@@ -418,6 +428,16 @@ jxl_status finalize_tables(jxl_ctx* c) {
                 c->wg3_item_count[k] = (int)(tab.size() / 4);
             }
         }
+    }
+    for (int k = 0; k < 2; k++) {
+        c->wave_item_count[k] = 0;
+        if (c->wave_segs.empty()) continue;
+        std::vector<int> tab;
+        wave_item_table(c->h_blocks.data(), c->bw, c->wave_segs.data(), (int)c->wave_segs.size(), k, tab);
+        if (tab.empty()) continue;
+        if (!c->wave_items[k].ensure(sizeof(int) * tab.size())) return fail(c, JXL_ERR_OOM, "device allocation failed (item list)");
+        HIP_TRY(c, hipMemcpy(c->wave_items[k].p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+        c->wave_item_count[k] = (int)(tab.size() / 4);
     }
     if (!items.empty())
         HIP_TRY(c, hipMemcpyAsync(c->items.p, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, c->stream));
@@ -635,6 +655,11 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->llf_ev, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->wave_fork_ev, hipEventDisableTiming);
+    for (int i = 0; i < 2; i++) {
+        (void)hipStreamCreateWithFlags(&c->wave_side[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->wave_join_ev[i], hipEventDisableTiming);
+    }
     if (const char* e = getenv("JXL_AUX_STREAMS")) c->n_aux = std::max(0, std::min((int)jxl_ctx::kAux, atoi(e)));
     for (int i = 0; i < c->n_aux; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
@@ -663,6 +688,11 @@ void jxl_ctx_destroy(jxl_ctx* c) {
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->llf_ev) (void)hipEventDestroy(c->llf_ev);
+    if (c->wave_fork_ev) (void)hipEventDestroy(c->wave_fork_ev);
+    for (int i = 0; i < 2; i++) {
+        if (c->wave_join_ev[i]) (void)hipEventDestroy(c->wave_join_ev[i]);
+        if (c->wave_side[i]) (void)hipStreamDestroy(c->wave_side[i]);
+    }
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     c->batch_args.release();
     c->batch_wg3_args.release();
@@ -677,6 +707,8 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     c->h_map16 = nullptr;
     c->wg3_items[0].release();
     c->wg3_items[1].release();
+    c->wave_items[0].release();
+    c->wave_items[1].release();
     c->batch_restore_args.release();
     for (int i = 0; i < jxl_ctx::kAux; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -1113,6 +1145,36 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 for (int q = 0; q < wl.n_seg; q++) any_llf = any_llf || wl.seg[q].type != 0;
             }
         }
+        // k_idct_wave: depends on nothing but the frame's inputs (its LLF is computed inside the items), so it starts at once
+        // on a side stream of its own and runs beside the LLF launch and the kernels of the other types
+        hipStream_t wave_stream[2] = {nullptr, nullptr};
+        WaveArgs wv[2];
+        static const bool wave_first = getenv("JXL_WAVE_FIRST") && atoi(getenv("JXL_WAVE_FIRST")) != 0;
+        {
+            const bool others = !c->type_launches.empty() || !c->special_launches.empty() || c->large_count > 0;
+            bool forked = false;
+            for (int k = 1; k >= 0; k--) {  // the 32-point class first: its items run longest
+                wv[k].n_items = 0;
+                if (c->wave_item_count[k] <= 0) continue;
+                wv[k].f = f;
+                wv[k].blocks = blocks;
+                wv[k].o0 = A[0]; wv[k].o1 = A[1]; wv[k].o2 = A[2];
+                wv[k].items = c->wave_items[k].as<int>();
+                wv[k].n_items = c->wave_item_count[k];
+                const bool last = !others && (k == 0 || c->wave_item_count[0] <= 0);  // the stage's last launch may use the main stream
+                wave_stream[k] = (!last && c->wave_side[k]) ? c->wave_side[k] : s;
+                if (wave_stream[k] != s) {
+                    if (!forked) (void)hipEventRecord(c->wave_fork_ev, s);
+                    forked = true;
+                    (void)hipStreamWaitEvent(wave_stream[k], c->wave_fork_ev, 0);
+                }
+                if (wave_first || !others) {
+                    launch_idct_wave(wv[k], k, wave_stream[k]);
+                    launches++;
+                    wv[k].n_items = 0;
+                }
+            }
+        }
         const int n_k = (int)c->type_launches.size() + (int)c->special_launches.size();
         const bool fork = n_k > 1 && c->n_aux > 0;
         if (wn[0] > 0 || wn[1] > 0) {
@@ -1191,6 +1253,19 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 }
         }
         if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
+        // launched behind the small grids of the other types (special 8x8, 64-point, 128/256-edge): those were dispatched first
+        // and hold their few wave slots; these launches' 64-thread workgroups fill everything else
+        for (int k = 1; k >= 0; k--) {
+            if (!wave_stream[k]) continue;
+            if (wv[k].n_items > 0) {
+                launch_idct_wave(wv[k], k, wave_stream[k]);
+                launches++;
+            }
+            if (wave_stream[k] != s) {
+                (void)hipEventRecord(c->wave_join_ev[k], wave_stream[k]);
+                (void)hipStreamWaitEvent(s, c->wave_join_ev[k], 0);
+            }
+        }
     }
     // Frame.invertSubsampling (Frame.java:457, 681-723): horizontal doublings, then vertical ones, per channel
     float* curp[3] = {A[0], A[1], A[2]};
@@ -1312,7 +1387,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
 bool batchable(const jxl_ctx* c) {
     for (const auto& sl : c->special_launches)
         if (!sl.wg_items) return false;  // k_idct_special_batch takes workgroup items
-    return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && (c->p.stages & JXL_STAGE_IDCT);
+    return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && c->wave_segs.empty() && (c->p.stages & JXL_STAGE_IDCT);
 }
 }  // namespace
 
