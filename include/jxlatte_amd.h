@@ -48,6 +48,13 @@ typedef int32_t jxl_status;
 #define JXL_TRANSFER_NONE 0 /* stop after invertXYB: linear float */
 #define JXL_TRANSFER_PQ   1 /* TransferFunction.TF_PQ.fromLinear, TransferFunction.java:83-87 */
 #define JXL_TRANSFER_SRGB 2 /* TransferFunction.TF_SRGB.fromLinearF, :39-44 */
+/* Tolerance of the PQ entries against the reference's (float)Math.pow(double) form. JXL_TRANSFER_PQ evaluates a table of
+ * quadratic segments (jxl_fastpow.h): over ALL 2^32 float inputs 99.96 % identical, the rest off by exactly 1 ulp, none worse
+ * (profiles/r2_pq_sweep.txt) -- so a quantised u8 / u16 sample can differ by 1 LSB where the float lands on a rounding
+ * boundary. JXL_TRANSFER_PQ_EXACT evaluates the same two pow() in double precision on the device (3x the instructions; the
+ * pre-round-2 form): use it where the samples must be the reference's bit for bit. Both are accepted by jxl_vardct_params.transfer
+ * and jxl_stage_transfer. */
+#define JXL_TRANSFER_PQ_EXACT 3
 #define JXL_OUT_F32 0       /* float planes */
 #define JXL_OUT_U16 1       /* ImageBuffer.castToIntWithMax(65535), ImageBuffer.java:129-147 */
 #define JXL_OUT_U8  2       /* ImageBuffer.castToIntWithMax(255) */
@@ -200,6 +207,9 @@ jxl_status jxl_vardct_put_group_i16(jxl_ctx* ctx, int32_t pass, int32_t group,
  * ever written) and is valid until the next begin_frame; commit is asynchronous (jxl_vardct_run is ordered behind it) and
  * may be followed by jxl_vardct_put_group for groups whose samples did not fit 16 bits, or for later passes. */
 jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* ctx, int16_t* planes[3], int32_t strides[3]);
+/* Rows of the three mapped planes ((paddedHeight >> jpegUpsamplingY[c]), HFCoefficients.java:64-69): plane c holds
+ * rows[c] * strides[c] samples. The JNI shim sizes its direct ByteBuffers from this, never from a caller-supplied count. */
+jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* ctx, int32_t rows[3]);
 jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* ctx);
 /* Page-locked host memory for the buffers that cross the bus (coefficient planes in, pixel planes out; a JNI caller wraps it
  * with NewDirectByteBuffer). put_group / put_group_i16 / read_output recognise such pointers: the copy is a direct DMA at

@@ -44,7 +44,8 @@ public final class NativeBackend implements AutoCloseable {
         int strideB);                                              // jxl_vardct_put_group_i16
     /** The frame's three int16 coefficient planes in page-locked memory the library owns (zero-filled): the entropy
      *  decoder stores its non-zero coefficients in place (row stride = plane width), then commitCoeffsI16(). */
-    public native ByteBuffer[] mapCoeffsI16(int rowsX, int rowsY, int rowsB); // jxl_vardct_map_coeffs_i16 + NewDirectByteBuffer (rows = paddedHeight >> jpegUpsamplingY[c])
+    public native ByteBuffer[] mapCoeffsI16();                     // jxl_vardct_map_coeffs_i16 + jxl_vardct_coeff_plane_rows + NewDirectByteBuffer
+    public native int[] coeffPlaneRows();                          // jxl_vardct_coeff_plane_rows -> rows of the three mapped planes
     public native void commitCoeffsI16();                          // jxl_vardct_commit_coeffs_i16
     /** Page-locked direct buffers for planes that cross the bus (coefficients in, pixels out). */
     public static native ByteBuffer hostAlloc(long bytes);         // jxl_host_alloc + NewDirectByteBuffer
@@ -73,6 +74,61 @@ public final class NativeBackend implements AutoCloseable {
     public native void planesYCbCr();                              // jxl_planes_ycbcr
     public native int[] planesShape();                             // jxl_planes_shape -> {height, width}
     public native void planesDownload(ByteBuffer p0, ByteBuffer p1, ByteBuffer p2); // jxl_planes_download
+    // ---- context, diagnostics
+    public static native String version();                         // jxl_version
+    public native void synchronize();                              // jxl_ctx_synchronize (JXLCodestreamDecoder.java:637: before the host reads)
+    public native long stream();                                   // jxl_ctx_stream (hipStream_t as a long, for callers that own a HIP runtime)
+    public native void setStream(long hipStream);                  // jxl_ctx_set_stream
+    public native void copyOutputDevice(long dstDevice);           // jxl_vardct_copy_output_device (D2D into an RCCL send buffer)
+    public native int outElemSize();                               // jxl_vardct_out_elem_size
+    public native int lastLaunchCount();                           // jxl_vardct_last_launch_count
+    public native void enableStageTiming(boolean on);              // jxl_vardct_enable_stage_timing
+    public native float lastStageMs(int which);                    // jxl_vardct_last_stage_ms (0 frame, 1 inverse transforms, 2 restoration)
+
+    // ---- stage entries: one reference function each, host planes in / out (what the parity tests drive)
+    public native void stageIdct2d(ByteBuffer src, ByteBuffer dst, int h, int w, boolean transposed);  // jxl_stage_idct2d (MathHelper.inverseDCT2D)
+    public native void stageFdct2d(ByteBuffer src, ByteBuffer dst, int h, int w);                      // jxl_stage_fdct2d (MathHelper.forwardDCT2D)
+    public native void stageGab(ByteBuffer i0, ByteBuffer i1, ByteBuffer i2, ByteBuffer o0, ByteBuffer o1, ByteBuffer o2, int h, int w,
+        float[] w1, float[] w2);                                   // jxl_stage_gab (Frame.performGabConvolution)
+    public native void stageEpf(ByteBuffer i0, ByteBuffer i1, ByteBuffer i2, ByteBuffer o0, ByteBuffer o1, ByteBuffer o2, int h, int w,
+        int iterations, ByteBuffer invSigma, float invSigmaModular, float[] channelScale, float pass0SigmaScale, float pass2SigmaScale,
+        float borderSadMul);                                       // jxl_stage_epf (Frame.performEdgePreservingFilter)
+    public native void stageEpfSigma(ByteBuffer hfMul, ByteBuffer sharpness, int bh, int bw, float globalScale, float[] sharpLut,
+        ByteBuffer invSigma);                                      // jxl_stage_epf_sigma (Frame.java:552-571)
+    public native void stageLfDequant(int lfgY, int lfgX, int cellsH, int cellsW, ByteBuffer qX, ByteBuffer qY, ByteBuffer qB,
+        int extraPrecision, float[] scaledDequant, int xFactorLF, int bFactorLF, boolean adaptiveSmoothing, float baseCorrX,
+        float baseCorrB, int colorFactor, ByteBuffer o0, ByteBuffer o1, ByteBuffer o2); // jxl_stage_lf_dequant (LFCoefficients)
+    public native void stageXyb(ByteBuffer p0, ByteBuffer p1, ByteBuffer p2, long n, float[] matrix, float[] opsinBias, float[] cbrtOpsinBias,
+        float intensityTarget);                                    // jxl_stage_xyb (OpsinInverseMatrix.invertXYB)
+    public native void stageYcbcr(ByteBuffer p0, ByteBuffer p1, ByteBuffer p2, long n);               // jxl_stage_ycbcr
+    public native void stageTransfer(ByteBuffer in, long n, int transfer, int maxValue, ByteBuffer outF, ByteBuffer outI); // jxl_stage_transfer
+    public native void stageInvHSqueeze(ByteBuffer avg, int aw, ByteBuffer res, int rw, int h, ByteBuffer out); // jxl_stage_inv_hsqueeze
+    public native void stageInvVSqueeze(ByteBuffer avg, int ah, ByteBuffer res, int rh, int w, ByteBuffer out); // jxl_stage_inv_vsqueeze
+    public native void stageRct(ByteBuffer v0, ByteBuffer v1, ByteBuffer v2, long n, int rctType);    // jxl_stage_rct
+    public native void stageModularToFloat(ByteBuffer a, ByteBuffer b, long n, float scale, ByteBuffer out); // jxl_stage_modular_to_float
+    public native void stageChromaUpsample(ByteBuffer in, int h, int w, int xShift, int yShift, ByteBuffer out); // jxl_stage_chroma_upsample
+    public static native float[] upsamplingWeights(int k, float[] packed);                            // jxl_upsampling_weights
+    public native void stageUpsample(ByteBuffer in, int h, int w, int k, float[] weights, ByteBuffer out); // jxl_stage_upsample
+    public native void stageNoiseInit(int h, int w, int groupDim, long seed0, int colors, ByteBuffer o0, ByteBuffer o1, ByteBuffer o2); // jxl_stage_noise_init
+    public native void stageNoiseAdd(ByteBuffer p0, ByteBuffer p1, ByteBuffer p2, ByteBuffer n0, ByteBuffer n1, ByteBuffer n2, long n,
+        float[] lut, float baseCorrX, float baseCorrB);            // jxl_stage_noise_add
+    /** rect: {h, w, canvasY, canvasX, frameY, frameX, refY, refX}. */
+    public native void stageBlend(int mode, int flags, boolean isInt, ByteBuffer canvas, int ch, int cw, ByteBuffer frame, int fh, int fw,
+        ByteBuffer ref, int rh, int rw, ByteBuffer frameAlpha, ByteBuffer refAlpha, int[] rect); // jxl_stage_blend
+    public native void stageOrient(ByteBuffer in, int h, int w, int orientation, ByteBuffer out);     // jxl_stage_orient
+    /** params: {height, width, nColor, hasAlpha, premultiplied, bitDepth, bigEndian, isInt[4], taggedDepth[4]}. */
+    public native void stagePack(ByteBuffer[] planes, int[] params, ByteBuffer out);                  // jxl_stage_pack
+
+    // ---- Modular: plan once (begin), run, read channel by channel
+    public static native int[] modularDefaultSqueezeParams(int[] widths, int[] heights, int nbMeta);  // jxl_modular_default_squeeze_params
+    public static native int[] modularSqueezedShapes(int[] widths, int[] heights, int[] squeezeParams); // jxl_modular_squeezed_shapes
+    public native void modularBegin(ByteBuffer[] chans, int[] widths, int[] heights, int[] squeezeParams, int rctType, int rctBegin); // jxl_modular_begin
+    public native void modularRun();                               // jxl_modular_run
+    public native int modularOutCount();                           // jxl_modular_out_count
+    public native int[] modularOutShape(int idx);                  // jxl_modular_out_shape -> {width, height}
+    public native void modularReadChannel(int idx, ByteBuffer dst); // jxl_modular_read_channel
+    public native int modularLastLaunchCount();                    // jxl_modular_last_launch_count
+    public native int modularRedoCount();                          // jxl_modular_redo_count
     /** channels: one direct buffer per encoded channel; squeezeParams: 4 ints per step. */
     public native void modularApply(ByteBuffer[] chans, int[] widths, int[] heights, int[] squeezeParams, int rctType,
         int rctBegin, ByteBuffer[] out, int[] outWidths, int[] outHeights); // jxl_modular_apply

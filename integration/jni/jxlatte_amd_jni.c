@@ -119,17 +119,24 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_putGroupI16
     CHECK(jxl_vardct_put_group_i16(c, pass, group, q, s));
 }
 
-/* planes of the current frame (sizes from the params the caller passed to beginFrame: (H >> sy) * (W >> sx) samples each) */
-JNIEXPORT jobjectArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_mapCoeffsI16(JNIEnv* e, jobject self, jint rx, jint ry, jint rb) {
+/* planes of the current frame: (H >> sy) rows of (W >> sx) samples each; the sizes come from the library
+ * (jxl_vardct_coeff_plane_rows), never from the caller */
+JNIEXPORT jobjectArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_mapCoeffsI16(JNIEnv* e, jobject self) {
     jxl_ctx* c = ctx_of(e, self);
     int16_t* pl[3];
-    int32_t st[3];
-    const jint h[3] = {rx, ry, rb};
+    int32_t st[3], rows[3];
     jxl_status r = jxl_vardct_map_coeffs_i16(c, pl, st);
+    if (r == JXL_OK) r = jxl_vardct_coeff_plane_rows(c, rows);
     if (r) { rethrow(e, c, r); return NULL; }
-    jobjectArray out = (*e)->NewObjectArray(e, 3, (*e)->FindClass(e, "java/nio/ByteBuffer"), NULL);
-    for (int i = 0; i < 3; i++)
-        (*e)->SetObjectArrayElement(e, out, i, (*e)->NewDirectByteBuffer(e, pl[i], (jlong)st[i] * h[i] * 2));
+    jclass bb = (*e)->FindClass(e, "java/nio/ByteBuffer");
+    if (!bb) return NULL;  /* exception pending */
+    jobjectArray out = (*e)->NewObjectArray(e, 3, bb, NULL);
+    if (!out) return NULL;
+    for (int i = 0; i < 3; i++) {
+        jobject b = (*e)->NewDirectByteBuffer(e, pl[i], (jlong)st[i] * rows[i] * 2);
+        if (!b || (*e)->ExceptionCheck(e)) return NULL;
+        (*e)->SetObjectArrayElement(e, out, i, b);
+    }
     return out;
 }
 
@@ -272,4 +279,347 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularAppl
         sp[i].horizontal = spv[4 * i]; sp[i].in_place = spv[4 * i + 1]; sp[i].begin_c = spv[4 * i + 2]; sp[i].num_c = spv[4 * i + 3];
     }
     CHECK(jxl_modular_apply(c, ci, n, sp, n_sp, rctType, rctBegin, co, n_out));
+}
+
+/* ---- context / diagnostics ---- */
+JNIEXPORT jstring JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_version(JNIEnv* e, jclass k) {
+    (void)k;
+    return (*e)->NewStringUTF(e, jxl_version());
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_synchronize(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_ctx_synchronize(c));
+}
+
+JNIEXPORT jlong JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stream(JNIEnv* e, jobject self) {
+    return (jlong)(intptr_t)jxl_ctx_stream(ctx_of(e, self));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_setStream(JNIEnv* e, jobject self, jlong hipStream) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_ctx_set_stream(c, (void*)(intptr_t)hipStream));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_copyOutputDevice(JNIEnv* e, jobject self, jlong dstDevice) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_vardct_copy_output_device(c, (void*)(intptr_t)dstDevice));
+}
+
+JNIEXPORT jint JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_outElemSize(JNIEnv* e, jobject self) {
+    return jxl_vardct_out_elem_size(ctx_of(e, self));
+}
+
+JNIEXPORT jint JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_lastLaunchCount(JNIEnv* e, jobject self) {
+    return jxl_vardct_last_launch_count(ctx_of(e, self));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_enableStageTiming(JNIEnv* e, jobject self, jboolean on) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_vardct_enable_stage_timing(c, on ? 1 : 0));
+}
+
+JNIEXPORT jfloat JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_lastStageMs(JNIEnv* e, jobject self, jint which) {
+    jxl_ctx* c = ctx_of(e, self);
+    float ms = 0.0f;
+    const jxl_status st = jxl_vardct_last_stage_ms(c, which, &ms);
+    if (st != JXL_OK) rethrow(e, c, st);
+    return ms;
+}
+
+JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_coeffPlaneRows(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    int32_t rows[3] = {0, 0, 0};
+    const jxl_status st = jxl_vardct_coeff_plane_rows(c, rows);
+    if (st != JXL_OK) { rethrow(e, c, st); return NULL; }
+    jintArray out = (*e)->NewIntArray(e, 3);
+    if (out) (*e)->SetIntArrayRegion(e, out, 0, 3, (const jint*)rows);
+    return out;
+}
+
+/* ---- stage entries: one reference function each (host planes in / out as direct buffers) ---- */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageIdct2d(JNIEnv* e, jobject self, jobject src, jobject dst, jint h, jint w,
+        jboolean transposed) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_idct2d(c, (const float*)ADDR(src), (float*)ADDR(dst), h, w, transposed ? 1 : 0));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageFdct2d(JNIEnv* e, jobject self, jobject src, jobject dst, jint h, jint w) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_fdct2d(c, (const float*)ADDR(src), (float*)ADDR(dst), h, w));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageGab(JNIEnv* e, jobject self, jobject i0, jobject i1, jobject i2, jobject o0,
+        jobject o1, jobject o2, jint h, jint w, jfloatArray w1, jfloatArray w2) {
+    jxl_ctx* c = ctx_of(e, self);
+    const float* in[3] = {(const float*)ADDR(i0), (const float*)ADDR(i1), (const float*)ADDR(i2)};
+    float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
+    float a[3], b[3];
+    (*e)->GetFloatArrayRegion(e, w1, 0, 3, a);
+    (*e)->GetFloatArrayRegion(e, w2, 0, 3, b);
+    CHECK(jxl_stage_gab(c, in, out, h, w, a, b));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageEpf(JNIEnv* e, jobject self, jobject i0, jobject i1, jobject i2, jobject o0,
+        jobject o1, jobject o2, jint h, jint w, jint iterations, jobject invSigma, jfloat invSigmaModular, jfloatArray channelScale,
+        jfloat pass0, jfloat pass2, jfloat borderSadMul) {
+    jxl_ctx* c = ctx_of(e, self);
+    const float* in[3] = {(const float*)ADDR(i0), (const float*)ADDR(i1), (const float*)ADDR(i2)};
+    float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
+    float cs[3];
+    (*e)->GetFloatArrayRegion(e, channelScale, 0, 3, cs);
+    CHECK(jxl_stage_epf(c, in, out, h, w, iterations, (const float*)ADDR(invSigma), invSigmaModular, cs, pass0, pass2, borderSadMul));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageEpfSigma(JNIEnv* e, jobject self, jobject hfMul, jobject sharpness, jint bh,
+        jint bw, jfloat globalScale, jfloatArray sharpLut, jobject invSigma) {
+    jxl_ctx* c = ctx_of(e, self);
+    float lut[8];
+    (*e)->GetFloatArrayRegion(e, sharpLut, 0, 8, lut);
+    CHECK(jxl_stage_epf_sigma(c, (const int32_t*)ADDR(hfMul), (const int32_t*)ADDR(sharpness), bh, bw, globalScale, lut, (float*)ADDR(invSigma)));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageLfDequant(JNIEnv* e, jobject self, jint lfgY, jint lfgX, jint cellsH,
+        jint cellsW, jobject qX, jobject qY, jobject qB, jint extraPrecision, jfloatArray scaledDequant, jint xFactorLF, jint bFactorLF,
+        jboolean adaptiveSmoothing, jfloat baseCorrX, jfloat baseCorrB, jint colorFactor, jobject o0, jobject o1, jobject o2) {
+    jxl_ctx* c = ctx_of(e, self);
+    jxl_lfquant_desc d;
+    memset(&d, 0, sizeof d);
+    d.lfg_y = lfgY; d.lfg_x = lfgX; d.cells_h = cellsH; d.cells_w = cellsW;
+    d.lf_quant[0] = (const int32_t*)ADDR(qX); d.lf_quant[1] = (const int32_t*)ADDR(qY); d.lf_quant[2] = (const int32_t*)ADDR(qB);
+    d.extra_precision = extraPrecision;
+    (*e)->GetFloatArrayRegion(e, scaledDequant, 0, 3, d.scaled_dequant);
+    d.x_factor_lf = xFactorLF; d.b_factor_lf = bFactorLF; d.adaptive_smoothing = adaptiveSmoothing ? 1 : 0;
+    float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
+    CHECK(jxl_stage_lf_dequant(c, &d, baseCorrX, baseCorrB, colorFactor, out));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageXyb(JNIEnv* e, jobject self, jobject p0, jobject p1, jobject p2, jlong n,
+        jfloatArray matrix, jfloatArray bias, jfloatArray cbrtBias, jfloat intensityTarget) {
+    jxl_ctx* c = ctx_of(e, self);
+    float* pl[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
+    float m[9], b[3], cb[3];
+    (*e)->GetFloatArrayRegion(e, matrix, 0, 9, m);
+    (*e)->GetFloatArrayRegion(e, bias, 0, 3, b);
+    (*e)->GetFloatArrayRegion(e, cbrtBias, 0, 3, cb);
+    CHECK(jxl_stage_xyb(c, pl, n, m, b, cb, intensityTarget));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageYcbcr(JNIEnv* e, jobject self, jobject p0, jobject p1, jobject p2, jlong n) {
+    jxl_ctx* c = ctx_of(e, self);
+    float* pl[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
+    CHECK(jxl_stage_ycbcr(c, pl, n));
+}
+
+/* transfer + quantise (PNGWriter.java:65,105-111): outF or outI is null */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageTransfer(JNIEnv* e, jobject self, jobject in, jlong n, jint transfer,
+        jint maxValue, jobject outF, jobject outI) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_transfer(c, (const float*)ADDR(in), n, transfer, maxValue, (float*)ADDR(outF), (int32_t*)ADDR(outI)));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageInvHSqueeze(JNIEnv* e, jobject self, jobject avg, jint aw, jobject res,
+        jint rw, jint h, jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_inv_hsqueeze(c, (const int32_t*)ADDR(avg), aw, (const int32_t*)ADDR(res), rw, h, (int32_t*)ADDR(out)));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageInvVSqueeze(JNIEnv* e, jobject self, jobject avg, jint ah, jobject res,
+        jint rh, jint w, jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_inv_vsqueeze(c, (const int32_t*)ADDR(avg), ah, (const int32_t*)ADDR(res), rh, w, (int32_t*)ADDR(out)));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageRct(JNIEnv* e, jobject self, jobject v0, jobject v1, jobject v2, jlong n,
+        jint rctType) {
+    jxl_ctx* c = ctx_of(e, self);
+    int32_t* v[3] = {(int32_t*)ADDR(v0), (int32_t*)ADDR(v1), (int32_t*)ADDR(v2)};
+    CHECK(jxl_stage_rct(c, v, n, rctType));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageModularToFloat(JNIEnv* e, jobject self, jobject a, jobject b, jlong n,
+        jfloat scale, jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_modular_to_float(c, (const int32_t*)ADDR(a), (const int32_t*)ADDR(b), n, scale, (float*)ADDR(out)));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageChromaUpsample(JNIEnv* e, jobject self, jobject in, jint h, jint w,
+        jint xShift, jint yShift, jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_chroma_upsample(c, (const float*)ADDR(in), h, w, xShift, yShift, (float*)ADDR(out)));
+}
+
+/* Frame.java:217-260 upsampling weights: packed (the bitstream's / default table) -> k * k * 25 floats */
+JNIEXPORT jfloatArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_upsamplingWeights(JNIEnv* e, jclass k_, jint k, jfloatArray packed) {
+    (void)k_;
+    jfloat* p = (*e)->GetFloatArrayElements(e, packed, NULL);
+    jfloatArray out = (*e)->NewFloatArray(e, k * k * 25);
+    if (!p || !out) return NULL;
+    jfloat* o = (*e)->GetFloatArrayElements(e, out, NULL);
+    const jxl_status st = o ? jxl_upsampling_weights(k, p, o) : JXL_ERR_OOM;
+    if (o) (*e)->ReleaseFloatArrayElements(e, out, o, 0);
+    (*e)->ReleaseFloatArrayElements(e, packed, p, JNI_ABORT);
+    if (st != JXL_OK) { rethrow(e, NULL, st); return NULL; }
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageUpsample(JNIEnv* e, jobject self, jobject in, jint h, jint w, jint k,
+        jfloatArray weights, jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    jfloat* wt = (*e)->GetFloatArrayElements(e, weights, NULL);
+    const jxl_status st = wt ? jxl_stage_upsample(c, (const float*)ADDR(in), h, w, k, wt, (float*)ADDR(out)) : JXL_ERR_OOM;
+    if (wt) (*e)->ReleaseFloatArrayElements(e, weights, wt, JNI_ABORT);
+    CHECK(st);
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageNoiseInit(JNIEnv* e, jobject self, jint h, jint w, jint groupDim,
+        jlong seed0, jint colors, jobject o0, jobject o1, jobject o2) {
+    jxl_ctx* c = ctx_of(e, self);
+    float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
+    CHECK(jxl_stage_noise_init(c, h, w, groupDim, (uint64_t)seed0, colors, out));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageNoiseAdd(JNIEnv* e, jobject self, jobject p0, jobject p1, jobject p2,
+        jobject n0, jobject n1, jobject n2, jlong n, jfloatArray lut, jfloat baseCorrX, jfloat baseCorrB) {
+    jxl_ctx* c = ctx_of(e, self);
+    float* pl[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
+    const float* nz[3] = {(const float*)ADDR(n0), (const float*)ADDR(n1), (const float*)ADDR(n2)};
+    float l[8];
+    (*e)->GetFloatArrayRegion(e, lut, 0, 8, l);
+    CHECK(jxl_stage_noise_add(c, pl, nz, n, l, baseCorrX, baseCorrB));
+}
+
+/* rect: {h, w, canvas_y, canvas_x, frame_y, frame_x, ref_y, ref_x} (JXLCodestreamDecoder.java:26-40, 285-422) */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageBlend(JNIEnv* e, jobject self, jint mode, jint flags, jboolean isInt,
+        jobject canvas, jint ch, jint cw, jobject frame, jint fh, jint fw, jobject ref, jint rh, jint rw, jobject frameAlpha, jobject refAlpha,
+        jintArray rect) {
+    jxl_ctx* c = ctx_of(e, self);
+    jint r[8];
+    (*e)->GetIntArrayRegion(e, rect, 0, 8, r);
+    jxl_blend_rect br;
+    br.h = r[0]; br.w = r[1]; br.canvas_y = r[2]; br.canvas_x = r[3]; br.frame_y = r[4]; br.frame_x = r[5]; br.ref_y = r[6]; br.ref_x = r[7];
+    CHECK(jxl_stage_blend(c, mode, (uint32_t)flags, isInt ? 1 : 0, ADDR(canvas), ch, cw, ADDR(frame), fh, fw, ADDR(ref), rh, rw,
+                          (const float*)ADDR(frameAlpha), (const float*)ADDR(refAlpha), &br));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageOrient(JNIEnv* e, jobject self, jobject in, jint h, jint w, jint orientation,
+        jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_stage_orient(c, ADDR(in), h, w, orientation, ADDR(out)));
+}
+
+/* params: {height, width, n_color, has_alpha, premultiplied, bit_depth, big_endian, is_int[4], tagged_depth[4]} (PNGWriter.java:79-111) */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stagePack(JNIEnv* e, jobject self, jobjectArray planes, jintArray params,
+        jobject out) {
+    jxl_ctx* c = ctx_of(e, self);
+    jint pv[15];
+    (*e)->GetIntArrayRegion(e, params, 0, 15, pv);
+    jxl_pack_params p;
+    p.height = pv[0]; p.width = pv[1]; p.n_color = pv[2]; p.has_alpha = pv[3]; p.premultiplied = pv[4]; p.bit_depth = pv[5]; p.big_endian = pv[6];
+    for (int i = 0; i < 4; i++) { p.is_int[i] = pv[7 + i]; p.tagged_depth[i] = pv[11 + i]; }
+    const void* pl[4] = {NULL, NULL, NULL, NULL};
+    const jsize n = (*e)->GetArrayLength(e, planes);
+    for (jsize i = 0; i < n && i < 4; i++) pl[i] = ADDR((*e)->GetObjectArrayElement(e, planes, i));
+    CHECK(jxl_stage_pack(c, pl, &p, ADDR(out)));
+}
+
+/* ---- Modular: plan once, run, read channel by channel (ModularStream.applyTransforms, ModularStream.java:110-131) ---- */
+JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularDefaultSqueezeParams(JNIEnv* e, jclass k, jintArray widths,
+        jintArray heights, jint nbMeta) {
+    (void)k;
+    const jsize n = (*e)->GetArrayLength(e, widths);
+    jint w[256], h[256];
+    jxl_squeeze_param sp[64];
+    if (n > 256) { rethrow(e, NULL, JXL_ERR_INVALID_ARGUMENT); return NULL; }
+    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
+    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
+    const int32_t cnt = jxl_modular_default_squeeze_params((const int32_t*)w, (const int32_t*)h, n, nbMeta, sp, 64);
+    if (cnt < 0) { rethrow(e, NULL, (jxl_status)cnt); return NULL; }
+    jintArray out = (*e)->NewIntArray(e, cnt * 4);
+    for (int32_t i = 0; out && i < cnt; i++) {
+        const jint v[4] = {sp[i].horizontal, sp[i].in_place, sp[i].begin_c, sp[i].num_c};
+        (*e)->SetIntArrayRegion(e, out, i * 4, 4, v);
+    }
+    return out;
+}
+
+/* returns {w0, h0, w1, h1, ...} of the channel list after the forward bookkeeping of the squeeze steps */
+JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularSqueezedShapes(JNIEnv* e, jclass k, jintArray widths,
+        jintArray heights, jintArray squeezeParams) {
+    (void)k;
+    const jsize n = (*e)->GetArrayLength(e, widths), n_sp = (*e)->GetArrayLength(e, squeezeParams) / 4;
+    jint w[256], h[256], spv[256];
+    int32_t ow[1024], oh[1024];
+    jxl_squeeze_param sp[64];
+    if (n > 256 || n_sp > 64) { rethrow(e, NULL, JXL_ERR_INVALID_ARGUMENT); return NULL; }
+    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
+    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
+    (*e)->GetIntArrayRegion(e, squeezeParams, 0, n_sp * 4, spv);
+    for (jsize i = 0; i < n_sp; i++) {
+        sp[i].horizontal = spv[4 * i]; sp[i].in_place = spv[4 * i + 1]; sp[i].begin_c = spv[4 * i + 2]; sp[i].num_c = spv[4 * i + 3];
+    }
+    const int32_t cnt = jxl_modular_squeezed_shapes((const int32_t*)w, (const int32_t*)h, n, sp, n_sp, ow, oh, 1024);
+    if (cnt < 0) { rethrow(e, NULL, (jxl_status)cnt); return NULL; }
+    jintArray out = (*e)->NewIntArray(e, cnt * 2);
+    for (int32_t i = 0; out && i < cnt; i++) {
+        const jint v[2] = {ow[i], oh[i]};
+        (*e)->SetIntArrayRegion(e, out, i * 2, 2, v);
+    }
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularBegin(JNIEnv* e, jobject self, jobjectArray chans, jintArray widths,
+        jintArray heights, jintArray squeezeParams, jint rctType, jint rctBegin) {
+    jxl_ctx* c = ctx_of(e, self);
+    const jsize n = (*e)->GetArrayLength(e, chans), n_sp = (*e)->GetArrayLength(e, squeezeParams) / 4;
+    if (n > 256 || n_sp > 64) {
+        rethrow(e, c, JXL_ERR_INVALID_ARGUMENT);
+        return;
+    }
+    jxl_channel ci[256];
+    jxl_squeeze_param sp[64];
+    jint w[256], h[256], spv[256];
+    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
+    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
+    (*e)->GetIntArrayRegion(e, squeezeParams, 0, n_sp * 4, spv);
+    for (jsize i = 0; i < n; i++) {
+        ci[i].width = w[i]; ci[i].height = h[i];
+        ci[i].data = (int32_t*)ADDR((*e)->GetObjectArrayElement(e, chans, i));
+    }
+    for (jsize i = 0; i < n_sp; i++) {
+        sp[i].horizontal = spv[4 * i]; sp[i].in_place = spv[4 * i + 1]; sp[i].begin_c = spv[4 * i + 2]; sp[i].num_c = spv[4 * i + 3];
+    }
+    CHECK(jxl_modular_begin(c, ci, n, sp, n_sp, rctType, rctBegin));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularRun(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_modular_run(c));
+}
+
+JNIEXPORT jint JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularOutCount(JNIEnv* e, jobject self) {
+    return jxl_modular_out_count(ctx_of(e, self));
+}
+
+JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularOutShape(JNIEnv* e, jobject self, jint idx) {
+    jxl_ctx* c = ctx_of(e, self);
+    int32_t wh[2] = {0, 0};
+    const jxl_status st = jxl_modular_out_shape(c, idx, &wh[0], &wh[1]);
+    if (st != JXL_OK) { rethrow(e, c, st); return NULL; }
+    jintArray out = (*e)->NewIntArray(e, 2);
+    if (out) (*e)->SetIntArrayRegion(e, out, 0, 2, (const jint*)wh);
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularReadChannel(JNIEnv* e, jobject self, jint idx, jobject dst) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_modular_read_channel(c, idx, (int32_t*)ADDR(dst)));
+}
+
+JNIEXPORT jint JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularLastLaunchCount(JNIEnv* e, jobject self) {
+    return jxl_modular_last_launch_count(ctx_of(e, self));
+}
+
+JNIEXPORT jint JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularRedoCount(JNIEnv* e, jobject self) {
+    return jxl_modular_redo_count(ctx_of(e, self));
 }

@@ -69,6 +69,7 @@ SIGNATURES = {
     "jxl_vardct_put_group": (i32, [vp, i32, i32, pi3, pi]),
     "jxl_vardct_put_group_i16": (i32, [vp, i32, i32, C.POINTER(C.POINTER(C.c_int16)), pi]),
     "jxl_vardct_map_coeffs_i16": (i32, [vp, C.POINTER(C.POINTER(C.c_int16)), pi]),
+    "jxl_vardct_coeff_plane_rows": (i32, [vp, pi]),
     "jxl_vardct_commit_coeffs_i16": (i32, [vp]),
     "jxl_host_alloc": (vp, [C.c_size_t]),
     "jxl_host_free": (None, [vp]),

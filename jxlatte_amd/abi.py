@@ -15,7 +15,7 @@ JXL_ERR_DEVICE = -4
 JXL_ERR_OOM = -5
 JXL_ERR_STATE = -6
 
-TRANSFER_NONE, TRANSFER_PQ, TRANSFER_SRGB = 0, 1, 2
+TRANSFER_NONE, TRANSFER_PQ, TRANSFER_SRGB, TRANSFER_PQ_EXACT = 0, 1, 2, 3
 OUT_F32, OUT_U16, OUT_U8, OUT_RGB8, OUT_RGB16 = 0, 1, 2, 3, 4
 BLEND_REPLACE, BLEND_ADD, BLEND_BLEND, BLEND_MULADD, BLEND_MULT = 0, 1, 2, 3, 4
 BLEND_FLAG_IS_ALPHA, BLEND_FLAG_HAS_EXTRA, BLEND_FLAG_CLAMP, BLEND_FLAG_PREMULT = 1, 2, 4, 8

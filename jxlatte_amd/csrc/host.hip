@@ -745,7 +745,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     if (p->width <= 0 || p->height <= 0 || (p->width & 7) || (p->height & 7))
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "padded frame size %dx%d must be positive multiples of 8", p->width, p->height);
     if (p->epf_iters < 0 || p->epf_iters > 3) return fail(c, JXL_ERR_INVALID_BITSTREAM, "epfIterations %d", p->epf_iters);
-    if (p->out_format < 0 || p->out_format > JXL_OUT_RGB16 || p->transfer < 0 || p->transfer > 2)
+    if (p->out_format < 0 || p->out_format > JXL_OUT_RGB16 || p->transfer < 0 || p->transfer > JXL_TRANSFER_PQ_EXACT)
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output stage selector");
     c->sub = false;
     for (int i = 0; i < 3; i++) {
@@ -1047,6 +1047,14 @@ jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* c, int16_t* planes[3], int32_t str
     return JXL_OK;
 }
 
+jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* c, int32_t rows[3]) {
+    if (!c) return JXL_ERR_INVALID_ARGUMENT;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    if (!rows) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null argument");
+    for (int ch = 0; ch < 3; ch++) rows[ch] = c->H >> c->sy[ch];
+    return JXL_OK;
+}
+
 jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* c) {
     jxl_status st = bind(c);
     if (st) return st;
@@ -1302,7 +1310,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
     if (do_gab || do_epf || do_xyb || do_out) {
         RestoreParams rp{};
         rp.gab = do_gab; rp.epf_iters = do_epf ? p.epf_iters : 0; rp.xyb = do_xyb;
-        rp.transfer = do_out ? p.transfer : JXL_TRANSFER_NONE;
+        rp.transfer = !do_out ? JXL_TRANSFER_NONE : p.transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : p.transfer;
         rp.max_value = do_out ? out_max_value(p.out_format) : 0;
         rp.out_elem = do_out ? out_elem_size(p.out_format) : 4;
         rp.interleaved = do_out && out_interleaved(p.out_format);
@@ -1313,7 +1321,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         }
         rp.xybp = make_xyb(p.opsin_matrix, p.opsin_bias, p.cbrt_opsin_bias, p.intensity_target);
         rp.global_scale_f = p.global_scale_f;
-        rp.pq_tab = c->pq_tab.as<float>();
+        rp.pq_tab = p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>();  // _EXACT: the double-precision form
         memcpy(rp.sharp_lut, p.epf_sharp_lut, sizeof rp.sharp_lut);
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
@@ -1361,7 +1369,8 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             const int es = out_elem_size(p.out_format);
             const bool il = out_interleaved(p.out_format);
             for (int i = 0; i < 3; i++) {
-                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer, maxv, c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, c->pq_tab.as<float>());
+                launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : p.transfer, maxv,
+                                c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>());
                 c->result[i] = c->outbuf[i].p;
                 launches++;
             }
@@ -1921,13 +1930,14 @@ jxl_status jxl_stage_transfer(jxl_ctx* c, const float* in, int64_t n, int32_t tr
                               int32_t* out_i) {
     jxl_status st = bind(c);
     if (st) return st;
-    if (!in || n < 0 || transfer < 0 || transfer > 2 || max_value < 0 || (max_value > 0 ? !out_i : !out_f))
+    if (!in || n < 0 || transfer < 0 || transfer > JXL_TRANSFER_PQ_EXACT || max_value < 0 || (max_value > 0 ? !out_i : !out_f))
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "transfer: bad arguments");
     Tmp t;
     float* di = t.up(in, (size_t)n);
     int32_t* dout = t.up<int32_t>(nullptr, (size_t)n);
     if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
-    launch_transfer(di, n, transfer, max_value, dout, 4, c->stream, 1, 0, c->pq_tab.as<float>());
+    launch_transfer(di, n, transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : transfer, max_value, dout, 4, c->stream, 1, 0,
+                    transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>());
     if ((st = finish(c))) return st;
     HIP_TRY(c, hipMemcpy(max_value > 0 ? (void*)out_i : (void*)out_f, dout, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return JXL_OK;

@@ -28,6 +28,7 @@
 //   * finalizeLLF runs as a small kernel of its own before (k_llf_wg3: one lane per LLF coefficient into the llf planes).
 // Bit-exactness: every sum keeps the reference's order, multiplies and adds are separate IEEE f32 operations.
 #include "jxl_internal.h"
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <vector>
@@ -774,8 +775,13 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.total_items = 0;
     a.img_floats = 0;
     a.items = nullptr;
-    for (int i = 0; i < n_seg && a.n_seg < Wg3Args::kMaxSeg; i++) {
+    static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
+    for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
+        if (a.n_seg >= Wg3Args::kMaxSeg) {  // a type twice in the list, or a new type without a larger kMaxSeg: never drop blocks silently
+            fprintf(stderr, "jxlatte_amd: build_wg3_args: more than %d segments\n", Wg3Args::kMaxSeg);
+            abort();
+        }
         Wg3Seg& sg = a.seg[a.n_seg++];
         const int nb = wg3_blocks_per_item(segs[i].type);
         sg.type = segs[i].type;

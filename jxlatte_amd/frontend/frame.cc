@@ -70,7 +70,10 @@ Channel sub_channel(const Channel& full, int dim, int idx) {
     Channel c(full.h, full.w, full.vshift, full.hshift);
     if (c.vshift < 0 || c.hshift < 0 || c.vshift > 30 || c.hshift > 30) throw BitstreamError("modular channel shift out of range");
     const int gh = dim >> c.vshift, gw = dim >> c.hshift;
-    if (gh <= 0 || gw <= 0) throw BitstreamError("modular channel shift larger than the group size");
+    // the reference divides by the group WIDTH only (Frame.java:284, 329: ArithmeticException when it is 0); a group HEIGHT of 0
+    // gives an empty sub-channel there (size.height = min(h, 0)), as in libjxl, and the stream decodes
+    if (gw <= 0) throw BitstreamError("modular channel shift larger than the group size");
+    if (gh <= 0) { c.h = c.w = 0; return c; }
     const int stride = ceil_div(c.w, gw);
     if (stride <= 0) { c.h = c.w = 0; return c; }
     c.oy = (idx / stride) * gh;

@@ -25,6 +25,20 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.jxl_version()
 
 
+def test_jni_shim_binds_every_declared_symbol():
+    """integration/jni cannot be compiled here (no JDK): what CAN be checked is that the C glue calls every function the header
+    declares and that the Java class and the C file name the same native methods"""
+    header = open(os.path.join(ROOT, "include", "jxlatte_amd.h")).read()
+    declared = set(re.findall(r"\b(jxl_[a-z0-9_]+)\s*\(", header))
+    c = open(os.path.join(ROOT, "integration", "jni", "jxlatte_amd_jni.c")).read()
+    used = set(re.findall(r"\b(jxl_[a-z0-9_]+)\s*\(", c))
+    assert not (declared - used), "header entries the JNI glue never calls: %s" % sorted(declared - used)
+    java = open(os.path.join(ROOT, "integration", "jni", "NativeBackend.java")).read()
+    natives = set(re.findall(r"native\s+[\w\[\]\.]+\s+(\w+)\s*\(", java))
+    cfun = set(re.findall(r"Java_com_traneptora_jxlatte_gpu_NativeBackend_(\w+)\(", c))
+    assert natives == cfun, (sorted(natives - cfun), sorted(cfun - natives))
+
+
 def test_frontend_library_exports_every_declared_symbol():
     from jxlatte_amd import frontend
     lib = frontend.load()

@@ -354,3 +354,42 @@ def test_wb_rainbow_colour_planes_cross_the_bus_once_each_way(device_backend):
     the other frames have host stages only (splines, as in the reference; the image is not XYB-encoded): nothing moves"""
     dec, _ = decode("wb-rainbow", device_backend)
     assert [s["plane_moves"] for s in dec.stats] == [["h2d", "d2h"], [], [], [], []]
+
+
+def test_vardct_lf_frame_keeps_its_xyb_planes(oracle_backend):
+    """a VarDCT frame with lf_level > 0 is stored in lfBuffer BEFORE the colour transform
+    (JXLCodestreamDecoder.java:615-617) and read back as XYB LF coefficients (LFCoefficients.java:44-57): the inverse XYB must not
+    be fused into it. lenna.jxl's frame is presented to the decode loop as an LF frame of level 1."""
+    from jxlatte_amd import decoder as dmod
+    dec = JXLDecoder(path("lenna"), backend=oracle_backend)
+    fused, planes_seen = [], []
+    orig_vf, orig_next = dec._vardct_frame, dec.fe.next_frame
+
+    def spy_vf(fr, fuse_xyb, keep=None):
+        fused.append(bool(fuse_xyb))
+        out = orig_vf(fr, fuse_xyb, keep)
+        planes_seen.append([np.array(p, copy=True) for p in out])
+        return out
+
+    def lf_next(*a):
+        fr = orig_next(*a)
+        if fr is not None:
+            fr.lf_level = 1
+            fr.type = dmod.LF_FRAME
+        return fr
+    dec._vardct_frame, dec.fe.next_frame = spy_vf, lf_next
+    try:
+        dec.decode()
+    except Exception:
+        pass  # a stream made of one LF frame produces no image: only the LF buffer matters here
+    assert fused == [False]
+    assert dec.lfBuffer[0] is not None
+    for c in range(3):
+        assert_bits_equal(dec.lfBuffer[0][c], planes_seen[0][c], "lfBuffer plane %d" % c)
+    # and those planes are XYB, not linear RGB: the same frame decoded normally has the colour transform applied
+    ref = JXLDecoder(path("lenna"), backend=oracle_backend)
+    seen = []
+    rvf = ref._vardct_frame
+    ref._vardct_frame = lambda fr, fuse, keep=None: (seen.append(bool(fuse)), rvf(fr, fuse, keep))[1]
+    ref.decode()
+    assert seen == [True]

@@ -112,6 +112,18 @@ def test_transfer_within_one_ulp(ctx, orc, tf):
         assert np.abs(gq - eq).max() <= 1 and (gq != eq).mean() < 1e-3
 
 
+def test_transfer_pq_exact_form(ctx, orc):
+    """JXL_TRANSFER_PQ_EXACT: the double-precision PQ on the device against the oracle's libm form -- the float
+    results may only differ where the double result sits within an ulp of double of a float rounding boundary"""
+    rng = np.random.default_rng(99)
+    x = np.concatenate([rng.random(200000), rng.random(20000) * 1e-3, rng.random(20000) * 4.0, [0.0, 1.0, 0.5]]).astype(F)
+    got, exp = host.transfer(ctx, x, abi.TRANSFER_PQ_EXACT), orc.transfer(x, abi.TRANSFER_PQ)
+    d = ulp_diff(got, exp)
+    assert d.max() <= 1 and (d != 0).mean() < 1e-4, (d.max(), (d != 0).mean())
+    gq, eq = host.transfer(ctx, x, abi.TRANSFER_PQ_EXACT, 65535), orc.transfer(x, abi.TRANSFER_PQ, 65535)
+    assert np.abs(gq - eq).max() <= 1 and (gq != eq).mean() < 1e-5
+
+
 @pytest.mark.parametrize("tf", [abi.TRANSFER_PQ, abi.TRANSFER_SRGB])
 def test_transfer_special_values_and_range(ctx, orc, tf):
     """Math.pow semantics of the inputs a frame can produce: negative (out-of-gamut) samples give NaN through PQ, zeros,
