@@ -138,7 +138,12 @@ struct jxl_ctx {
     // fork/join side streams: the per-type IDCT kernels are independent and individually too small to fill
     // 256 CUs, so they run concurrently
     static constexpr int kAux = 12;
-    int n_aux = 1;  // side streams in use (JXL_AUX_STREAMS overrides). 1 is the batch-throughput optimum; 3 gives the lowest single-frame latency
+    // side streams in use (JXL_AUX_STREAMS overrides). HIP maps streams onto 4 hardware queues round-robin in creation order,
+    // process-wide, and kernels of streams that share a queue run one after the other: with main + ONE side stream per context the
+    // main streams of a batch of contexts alternate between two queues and the side streams between the other two. Measured
+    // (r3, 8 contexts x 4K frames, same box): streams per context 2 -> 48.9 Gpx/s, 3 -> 40.8, 4 -> 41.4 (every main stream on ONE
+    // queue), 5 -> 45.3, 6 -> 46.7, 7 -> 40.0, 8 -> 40.7. So: no stream is created that is not used.
+    int n_aux = 1;
     hipStream_t aux[kAux] = {};
     hipEvent_t fork_ev = nullptr, llf_ev = nullptr, join_ev[kAux] = {};
     hipStream_t wave_side[2] = {nullptr, nullptr};  // k_idct_wave's own side streams (it waits for nothing but the frame's inputs)
@@ -656,11 +661,17 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->llf_ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->wave_fork_ev, hipEventDisableTiming);
-    for (int i = 0; i < 2; i++) {
+    // (only where the experimental wave kernels are switched on: every stream a context creates shifts the round-robin mapping
+    // of all later streams onto the 4 hardware queues -- see n_aux)
+    for (int i = 0; i < 2 && wave_handles(0); i++) {
         (void)hipStreamCreateWithFlags(&c->wave_side[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->wave_join_ev[i], hipEventDisableTiming);
     }
     if (const char* e = getenv("JXL_AUX_STREAMS")) c->n_aux = std::max(0, std::min((int)jxl_ctx::kAux, atoi(e)));
+    // (r3: side streams created with hipStreamCreateWithPriority at the highest priority -- meant to keep the few long-running
+    // workgroups of the 64-point and special launches from queueing behind the machine-filling main launch -- started those
+    // launches ~50 us LATER and ran them one after the other: single frame 310 against 233 us, batch 35.5 against 39.9 Gpx/s.
+    // Default-priority streams stay.)
     for (int i = 0; i < c->n_aux; i++) {
         (void)hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming);
@@ -1135,7 +1146,11 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             return fc;
         };
         // classes 2 / 3 (k_idct_wg3.hip): argument blocks of the two persistent launches and of the LLF launch in front
-        static const int wg3_grid = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 768;
+        // 512 = two 256-thread workgroups per CU (r3; was 768): at 128 VGPRs three of them leave one wave slot per SIMD, and a
+        // workgroup of the 64-point launch (512 threads: two waves per SIMD) then fits on no CU until a persistent workgroup of
+        // this launch retires -- at its end. With two per CU all 110 workgroups of the 64-point launch are resident at once
+        // beside it: single 4K frame 231 -> 214 us, IDCT stage 134 -> 117 us, batch unchanged (49.0 / 48.9 Gpx/s, same box)
+        static const int wg3_grid = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 512;
         static const int wg3_grid_big = getenv("JXL_WG3_GRID_BIG") ? atoi(getenv("JXL_WG3_GRID_BIG")) : 512;
         Wg3Args wa[2], wl;
         int wn[2] = {0, 0};
