@@ -745,7 +745,8 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     (void)hipEventCreateWithFlags(&c->wave_fork_ev, hipEventDisableTiming);
     // (only where the experimental wave kernels are switched on: every stream a context creates shifts the round-robin mapping
     // of all later streams onto the 4 hardware queues -- see n_aux)
-    for (int i = 0; i < 2 && wave_handles(0); i++) {
+    static const bool wave_own_streams = !(getenv("JXL_WAVE_STREAMS") && atoi(getenv("JXL_WAVE_STREAMS")) == 0);
+    for (int i = 0; i < 2 && wave_handles(0) && wave_own_streams; i++) {
         (void)hipStreamCreateWithFlags(&c->wave_side[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->wave_join_ev[i], hipEventDisableTiming);
     }
