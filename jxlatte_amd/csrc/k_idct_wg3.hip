@@ -510,7 +510,15 @@ struct Body {
             idct1d3<KC, W>(acc, lut_w + kc_row * (KC / 2), r0, r1, r2, 1);
             pre_store();
             STAMP3(7);
+#ifdef JXL_ABL_WG3_NOSTORE  // timing experiment: the outputs are kept alive, nothing is stored
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int kk = 0; kk < KC; kk++) asm volatile("" ::"v"(acc.get(ch, kk)));
+            if (false) {
+#else
             if (rb < it.nb) {
+#endif
                 float* o3[3] = {a.o0, a.o1, a.o2};
                 const int cy = (int)((uint32_t)rrec.x & 0xffffu), cx = (int)((uint32_t)rrec.x >> 16);
                 const int64_t off = (int64_t)(cy * 8 + ry) * f.width + cx * 8;
