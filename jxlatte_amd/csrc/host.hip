@@ -339,6 +339,8 @@ jxl_status finalize_tables(jxl_ctx* c) {
             DevBlock bad{};
         };
         std::vector<Part> parts((size_t)n_thr);
+        for (Part& P : parts)
+            for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) P.sm[t].reserve(t_count[t] / (size_t)n_thr + (n_thr > 1 ? t_count[t] / 8 + 16 : 0));
         auto work = [&](int t) {
             Part& P = parts[(size_t)t];
             const int g0 = (int)((int64_t)n_groups * t / n_thr), g1 = (int)((int64_t)n_groups * (t + 1) / n_thr);
@@ -376,6 +378,10 @@ jxl_status finalize_tables(jxl_ctx* c) {
             if (P.err == 2) return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock spans too many tiles");
         }
         for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
+            if (n_thr == 1) {
+                sm[t].swap(parts[0].sm[t]);
+                continue;
+            }
             sm[t].reserve(t_count[t]);
             for (const Part& P : parts) sm[t].insert(sm[t].end(), P.sm[t].begin(), P.sm[t].end());
         }

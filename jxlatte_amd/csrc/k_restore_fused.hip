@@ -6,11 +6,13 @@
 // OpsinInverseMatrix.java:105-142, JXLImage.java:244-258, ImageBuffer.java:129-147) and is checked
 // bit-for-bit against them through the oracle AND against the stage kernels.
 //
-// Geometry (template <GAB, ITERS>): the most expensive stage -- the first EPF iteration that runs -- is
-// computed on a 64x32 window = 256 threads x (4 wide x 2 tall) register patches. Later iterations
-// shrink the window by their radius (iteration 1: 2 px of input halo, iteration 2: 1, iteration 0: 3),
-// Gaborish adds 1. E.g. the default (Gab + iterations 1,2): input tile 70x38 -> Gab 68x36 -> EPF1 64x32
-// -> EPF2 62x30 output tile. Two LDS buffers (ping-pong) of 3 planes each.
+// Geometry (template <GAB, ITERS, PLAIN, PH>): the most expensive stage -- the first EPF iteration that runs -- is computed on a
+// 64x32 window = 512 threads x (4 wide x 1 tall) register patches (PH = 2: 256 threads x 4x2 patches, measured slower). Later
+// iterations shrink the window by their radius (iteration 1: 2 px of input halo, iteration 2: 1, iteration 0: 3), Gaborish
+// adds 1. E.g. the default (Gab + iterations 1,2): input tile 70x38 -> Gab 68x36 -> EPF1 64x32 -> EPF2 62x30 output tile.
+// ONE LDS image of 3 planes (~34 KB) that every stage updates IN PLACE: a thread computes the patch it owns into registers, the
+// workgroup meets at a barrier (all reads of the old values done), then the patches are written back over the input
+// (4 workgroups per CU = 8 waves per SIMD at 63 VGPRs).
 //
 // Exactness: per pixel the EPF distance is the reference's strictly sequential sum
 //   dist = (((0 + |a-b|*s0) + ...)            channel-major, cross order (0,0),(0,-1),(0,1),(-1,0),(1,0)
