@@ -514,7 +514,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
             c->wg3_item_count[k] = 0;
             for (const auto& tl : c->type_launches) {
                 if (tl.cls != 2 + k || !spatial) continue;
-                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, tab);
+                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, tab, wg3_grid_cap(k == 1));
                 if (tab.empty()) continue;
                 if (!c->wg3_items[k].ensure(sizeof(int) * tab.size())) return fail(c, JXL_ERR_OOM, "device allocation failed (item list)");
                 HIP_TRY(c, hipMemcpy(c->wg3_items[k].p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
@@ -1237,8 +1237,8 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         // workgroup of the 64-point launch (512 threads: two waves per SIMD) then fits on no CU until a persistent workgroup of
         // this launch retires -- at its end. With two per CU all 110 workgroups of the 64-point launch are resident at once
         // beside it: single 4K frame 231 -> 214 us, IDCT stage 134 -> 117 us, batch unchanged (49.0 / 48.9 Gpx/s, same box)
-        static const int wg3_grid = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 512;
-        static const int wg3_grid_big = getenv("JXL_WG3_GRID_BIG") ? atoi(getenv("JXL_WG3_GRID_BIG")) : 512;
+        static const int wg3_grid = wg3_grid_cap(false);
+        static const int wg3_grid_big = wg3_grid_cap(true);
         Wg3Args wa[2], wl;
         int wn[2] = {0, 0};
         bool any_llf = false;

@@ -114,7 +114,8 @@ struct Wg3Args {
     Wg3Seg seg[kMaxSeg];
 };
 // the item list of one class's segments in spatial order, dealt to the XCDs in runs (host side)
-void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out);
+void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out, int grid);
+int wg3_grid_cap(bool big);  // workgroups of a single-frame launch (JXL_WG3_GRID / JXL_WG3_GRID_BIG)
 bool wg3_handles(int type);
 bool wg3_big(int type);  // the 64-point family: its own launch (register / LDS class)
 int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],

@@ -55,8 +55,14 @@ __device__ unsigned long long* g_stamps3 = nullptr;
     do {                                                                                                                 \
         if (g_stamps3 && threadIdx.x == 0 && it_no < 2) g_stamps3[((size_t)blockIdx.x * 2 + it_no) * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// workgroup lifetime: entry time, exit time and items done in column 11 of the workgroup's two rows + a third table behind them
+#define STAMP3_LIFE(row, val)                                                                                            \
+    do {                                                                                                                 \
+        if (g_stamps3 && threadIdx.x == 0) g_stamps3[((size_t)blockIdx.x * 2 + (row)) * 12 + 11] = (val);                  \
+    } while (0)
 #else
 #define STAMP3(i)
+#define STAMP3_LIFE(row, val)
 #endif
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() carries a workgroup-scope release fence over ALL address
@@ -615,6 +621,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     int gi = (int)blockIdx.x;
     Item cur = item_of<P>(a, gi);
     if (cur.type < 0) return;
+    STAMP3_LIFE(0, __builtin_amdgcn_s_memtime());
     float* img = lds;
     float* qtab = lds + a.img_floats;  // [3][64]: 0, quantBias[c], (float)a - qbn / (float)a
     if (tid0 < 192) {
@@ -673,6 +680,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         STAMP3(10);
         it_no++;
     }
+    STAMP3_LIFE(1, __builtin_amdgcn_s_memtime() | ((unsigned long long)(it_no + 1) << 56));
 }
 
 template <bool BIG>
@@ -758,6 +766,12 @@ bool wg3_handles(int type) {
 }
 bool wg3_big(int type) { return type == 18 || type == 19 || type == 20; }
 
+int wg3_grid_cap(bool big) {
+    static const int g_small = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 512;
+    static const int g_big = getenv("JXL_WG3_GRID_BIG") ? atoi(getenv("JXL_WG3_GRID_BIG")) : 512;
+    return big ? g_big : g_small;
+}
+
 int wg3_blocks_per_item(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
     return ((h > w ? h : w) <= 32 ? 2048 : 4096) / (h * w);
@@ -809,7 +823,27 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
 // lists are group-major already, so an item's blocks are neighbours) and dealt to the XCDs in runs of about one group's
 // items: workgroup w takes items w, w + G, ...; with G a multiple of 8 item i runs on XCD i % 8, so a run's items -- the
 // ones that share lines -- are in flight together behind ONE L2.
-void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out) {
+//
+// Balance (r3). The persistent grid takes list positions w, w + G, ...: a workgroup gets ~13 items of a 4K frame, their types as
+// the spatial order happens to deal them, and an item of 32-point blocks costs 1.8x one of 8-point blocks: the slowest of 512
+// workgroups ran 25 % longer than the average one (SQ_WAVE_CYCLES / waves = 57 us of a 73 us launch, default mix; 52 of 60 for a
+// frame of DCT8 only). With `grid` given, the items of every round k (positions [kG, (k+1)G)) are permuted among the positions of
+// the same XCD (same position mod 8: the run / L2 pairing stays, and so does the time at which a region is touched): the costliest
+// item of the round goes to the workgroup with the least work so far. Every position keeps an item, so a launch with another
+// grid (the batch path) is still correct, only unbalanced.
+static float wg3_item_cost(int type) {  // us per 4K frame tiled with the type, i.e. relative cost of 2048 positions
+    switch (type) {
+    case 0: return 55.f;
+    case 4: return 76.f;
+    case 5: return 100.f;
+    case 6: case 7: return 67.f;
+    case 8: case 9: return 83.f;
+    case 10: case 11: return 90.f;
+    default: return 100.f;
+    }
+}
+
+void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out, int grid) {
     struct Rec { uint32_t key; int type, first, nb; };
     std::vector<Rec> recs;
     static const int rsh = getenv("JXL_WG3_REGION_SHIFT") ? std::min(12, std::max(0, atoi(getenv("JXL_WG3_REGION_SHIFT")))) : 5;
@@ -830,12 +864,41 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
     for (auto& v : q) longest = std::max(longest, v.size());
     out.clear();
     out.reserve(recs.size() * 4);
+    std::vector<const Rec*> lst;
+    lst.reserve(recs.size());
     for (size_t i = 0; i < longest; i++)
         for (int x = 0; x < 8; x++)
-            if (i < q[x].size()) {
-                const Rec& r = *q[x][i];
-                out.push_back(r.type); out.push_back(r.first); out.push_back(r.nb); out.push_back(0);
+            if (i < q[x].size()) lst.push_back(q[x][i]);
+    static const bool balance = !(getenv("JXL_WG3_BALANCE") && atoi(getenv("JXL_WG3_BALANCE")) == 0);
+    const size_t N = lst.size(), G = (size_t)std::max(0, grid);
+    if (balance && G >= 8 && G % 8 == 0 && N > G) {
+        std::vector<float> load(G, 0.0f);
+        std::vector<const Rec*> its;
+        std::vector<int> wgs;
+        const size_t rounds = (N + G - 1) / G;
+        // the last (possibly partial) round first: its positions are fixed to the first workgroups, the full rounds then even out
+        for (size_t rr = 0; rr < rounds; rr++) {
+            const size_t k = rr == 0 ? rounds - 1 : rr - 1;
+            const size_t p0 = k * G, p1 = std::min(N, p0 + G);
+            for (int x = 0; x < 8; x++) {
+                its.clear();
+                wgs.clear();
+                for (size_t p = p0 + x; p < p1; p += 8) {
+                    its.push_back(lst[p]);
+                    wgs.push_back((int)(p - p0));
+                }
+                std::stable_sort(its.begin(), its.end(), [](const Rec* a, const Rec* b) { return wg3_item_cost(a->type) > wg3_item_cost(b->type); });
+                std::stable_sort(wgs.begin(), wgs.end(), [&](int a, int b) { return load[a] < load[b]; });
+                for (size_t i = 0; i < its.size(); i++) {
+                    lst[p0 + wgs[i]] = its[i];
+                    load[wgs[i]] += wg3_item_cost(its[i]->type);
+                }
             }
+        }
+    }
+    for (const Rec* r : lst) {
+        out.push_back(r->type); out.push_back(r->first); out.push_back(r->nb); out.push_back(0);
+    }
 }
 
 // LLF coefficients of the class's blocks into the llf planes (must precede launch_idct_wg3 on the same stream)

@@ -113,4 +113,24 @@ for m in [m for m in args.mixes.split(",") if m]:
     # a named mix, or an explicit one: DCT8=0.5+DCT16=0.5
     mix = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in m.split("+")} if "=" in m else m
     frame = synth.make_vardct_frame(W, H, seed=1234, mix=mix)
-    measure(frame, "mix:" + m)
+    fr = measure(frame, "mix:" + m)
+    if stamp_buf is not None:
+        import torch
+        stamp3.zero_()
+        torch.cuda.synchronize()
+        fr.run()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        s3 = stamp3.cpu().numpy().astype(np.uint64)
+        t_in, t_out = s3[0::2, 11], s3[1::2, 11]
+        ok = t_in != 0
+        t_in, cnt, t_out = t_in[ok].astype(np.int64), (t_out[ok] >> np.uint64(56)).astype(np.int64), (t_out[ok] & np.uint64((1 << 56) - 1)).astype(np.int64)
+        t0 = t_in.min()
+        life = t_out - t_in
+        print("   wg3 lifetimes of %d workgroups (cycles of s_memtime): entry p50 %d p90 %d max %d | life p10 %d p50 %d p90 %d max %d | exit p10 %d p50 %d p90 %d max %d | items %d..%d"
+              % (len(t_in), np.median(t_in - t0), np.percentile(t_in - t0, 90), (t_in - t0).max(), np.percentile(life, 10), np.median(life),
+                 np.percentile(life, 90), life.max(), np.percentile(t_out - t0, 10), np.median(t_out - t0), np.percentile(t_out - t0, 90),
+                 (t_out - t0).max(), cnt.min(), cnt.max()))
+        for x in range(8):
+            sel = (np.nonzero(ok)[0] % 8) == x
+            print("      XCD %d: life p50 %d max %d, exit max %d" % (x, np.median(life[sel]), life[sel].max(), (t_out[sel] - t0).max()))
