@@ -1252,7 +1252,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 }
             if (!all.empty()) {
                 build_wg3_args(f, blocks, all.data(), (int)all.size(), 2, A, wl);
-                for (int q = 0; q < wl.n_seg; q++) any_llf = any_llf || wl.seg[q].type != 0;
+                for (int q = 0; q < wl.n_seg; q++) any_llf = any_llf || (wl.seg[q].type != 0 && !wl.llf_in_item);
             }
         }
         // k_idct_wave: depends on nothing but the frame's inputs (its LLF is computed inside the items), so it starts at once
@@ -1298,6 +1298,17 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 (void)hipEventRecord(c->fork_ev, s);
                 (void)hipStreamWaitEvent(side, c->fork_ev, 0);
             }
+            static const int plan = getenv("JXL_WG3_PLAN") ? atoi(getenv("JXL_WG3_PLAN")) : 0;
+            // With finalizeLLF inside the items no IDCT launch depends on another. The 64-point launch is ONE round of items (a
+            // 4K frame of the default mix has ~100 of them for 110 workgroups), i.e. its duration is the latency of a single
+            // item -- 28 us alone on the device, 58-72 us beside the other class's workgroups -- so it goes first on the side
+            // stream and the 8x8 special kernel (24 us) behind it, not in front of it
+            static const bool big_first = !(getenv("JXL_WG3_BIG_FIRST") && atoi(getenv("JXL_WG3_BIG_FIRST")) == 0);
+            const bool big_early = big_first && plan != 1 && !any_llf && wn[1] > 0;
+            if (big_early) {
+                launch_idct_wg3(wa[1], true, wg3_grid_big, side);
+                launches++;
+            }
             for (const auto& sl : c->special_launches) {
                 launch_idct_special(frame_of(sl.channel), blocks, items + sl.items_off, sl.n_items, A, side, sl.wg_items);
                 launches++;
@@ -1311,7 +1322,6 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                     (void)hipStreamWaitEvent(side, c->llf_ev, 0);
                 }
             }
-            static const int plan = getenv("JXL_WG3_PLAN") ? atoi(getenv("JXL_WG3_PLAN")) : 0;
             hipStream_t s_small = plan == 1 ? side : s, s_big = plan == 1 ? s : side;
             if (plan == 1 && fork && any_llf && wn[0] > 0 && wn[1] <= 0) {
                 (void)hipEventRecord(c->llf_ev, s);
@@ -1325,7 +1335,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 launch_idct_wg3(wa[0], false, wg3_grid, s_small);
                 launches++;
             }
-            if (plan != 1 && wn[1] > 0) {
+            if (plan != 1 && wn[1] > 0 && !big_early) {
                 launch_idct_wg3(wa[1], true, wg3_grid_big, s_big);
                 launches++;
             }
@@ -1600,7 +1610,7 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
                 if (items <= 0) continue;
                 if (cls != 10 && c->wg3_item_count[cls - 11] == items) a.items = c->wg3_items[cls - 11].as<int>();
                 if (cls == 10) {
-                    const int64_t nl = wg3_llf_count(a);
+                    const int64_t nl = a.llf_in_item ? 0 : wg3_llf_count(a);  // the items do finalizeLLF themselves: no launch
                     if (nl <= 0) continue;
                     max_n = std::max(max_n, nl);
                 } else {

@@ -231,8 +231,8 @@ __device__ __forceinline__ void idct1d3(Acc3<KC>& acc, cfloatp lut /* row 0, lan
 // One LLF coefficient (ky, kx) of channel plane lfp (patch origin, stride bw): forwardDCT2D of the DSH x DSW LF patch
 // (MathHelper.java:124-136: rows, then columns) times llfScale (HFCoefficients.java:194-229). Every lane recomputes the
 // row-pass values it needs: same operations in the same order as the reference's shared scratch arrays.
-template <int DSH, int DSW>
-__device__ __forceinline__ float llf_coeff3(const float* __restrict__ lut_all, const float* __restrict__ lfp, int bw, int ky, int kx) {
+template <int DSH, int DSW, typename ScaleTab>
+__device__ __forceinline__ float llf_coeff3(const float* __restrict__ lut_all, const float* __restrict__ lfp, int bw, int ky, int kx, ScaleTab llf_scale) {
     const float* lutw = lut_all + lut_off(clog2(DSW));
     const float* luth = lut_all + lut_off(clog2(DSH));
     const float invw = 1.0f / (float)DSW, invh = 1.0f / (float)DSH;
@@ -266,7 +266,7 @@ __device__ __forceinline__ float llf_coeff3(const float* __restrict__ lut_all, c
     }
     constexpr int yll = DSH <= 1 ? 0 : DSH <= 2 ? 1 : DSH <= 4 ? 2 : 3;
     constexpr int xll = DSW <= 1 ? 0 : DSW <= 2 ? 1 : DSW <= 4 ? 2 : 3;
-    return (d2 * invh) * (kLlfScale3[ky << (5 - yll)] * kLlfScale3[kx << (5 - xll)]);
+    return (d2 * invh) * (llf_scale[ky << (5 - yll)] * llf_scale[kx << (5 - xll)]);
 }
 
 // ---- work items ---------------------------------------------------------------------------------------------------
@@ -384,15 +384,16 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             raw.ok |= 1u << j;
         }
     }
-    // finalizeLLF result (k_llf_wg3 wrote it into the block's own cells of the llf planes): lane t < nb * PER_B holds
-    // coefficient (c, ky, kx) = t % PER_B of block t / PER_B
+    // finalizeLLF input: lane t < nb * PER_B holds LF sample (c, y, x) = t % PER_B of block t / PER_B (for an 8x8 block that IS
+    // its LLF coefficient); the lanes exchange them through the LDS patch table and dequant() transforms them (r3: this was a
+    // kernel of its own in front of the launch, k_llf_wg3 -- 9 us + a dependent launch on every frame's critical path)
     const int dsh = H >> 3, dsw = W >> 3, per_b = 3 * dsh * dsw;
     const int bl = tid / per_b;
     if (it.type >= 0 && bl < it.nb) {
         const int rr = tid - bl * per_b, c = rr / (dsh * dsw), k = rr - c * (dsh * dsw);
         const int ky = k / dsw, kx = k - ky * dsw;
         const int cy = (int)((uint32_t)rc.lx & 0xffffu), cx = (int)((uint32_t)rc.lx >> 16);
-        raw.llf = f.llf[c][(int64_t)(cy + ky) * f.bw + cx + kx];
+        raw.llf = (a.llf_in_item ? f.lf[c] : f.llf[c])[(int64_t)(cy + ky) * f.bw + cx + kx];
     }
 }
 
@@ -466,7 +467,13 @@ struct Body {
             const int b = tid / C::PER_B, rr = tid % C::PER_B;
             if (b < it.nb) {
                 const int c = rr / (C::DSH * C::DSW), k = rr % (C::DSH * C::DSW);
-                img[(c * C::NB + b) * C::IMG + (k / C::DSW) * C::LD + (k % C::DSW)] = raw.llf;
+                float v = raw.llf;
+                if (C::DSH * C::DSW > 1 && a.llf_in_item) {
+                    // forwardDCT2D of the block's LF patch, which the item's lanes published in lf_patch[] one barrier ago
+                    const float* aux = qtab + 192;  // [70] cosine LUT of 2, 4, 8 points | [2] | [32] LLF scale | [192] LF patches
+                    v = llf_coeff3<C::DSH, C::DSW>(aux, aux + 104 + b * C::PER_B + c * (C::DSH * C::DSW), C::DSW, k / C::DSW, k % C::DSW, aux + 72);
+                }
+                img[(c * C::NB + b) * C::IMG + (k / C::DSW) * C::LD + (k % C::DSW)] = v;
             }
         }
     }
@@ -628,6 +635,12 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         const int c = tid0 >> 6, aq = tid0 & 63;
         qtab[tid0] = aq == 0 ? 0.0f : aq == 1 ? a.f.quant_bias[c] : (float)aq - a.f.quant_bias_numerator / (float)aq;
     }
+    // finalizeLLF inside the item: the cosine tables of 2, 4 and 8 points (the first 70 floats of the LUT), the LLF scale
+    // table and one LF sample per LLF coefficient of the coming item (lf_patch, written when the item's prefetch has landed)
+    float* aux = qtab + 192;
+    float* lf_patch = aux + 104;
+    if (tid0 < 70) aux[tid0] = a.f.lut[tid0];
+    else if (tid0 >= 72 && tid0 < 104) aux[tid0] = kLlfScale3[tid0 - 72];
     Raw<NG, WS> raw;
     Recs<NG> rc;
     load_recs<T, NG>(a, cur, tid0, rc);
@@ -651,7 +664,14 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         asm volatile("" ::"v"(raw.llf), "v"(rc.lx));
     };
     loads_landed();
-    lds_barrier();  // qtab
+    if (tid0 < 192) lf_patch[tid0] = raw.llf;
+    lds_barrier();  // qtab, aux, lf_patch
+    // the next item's patches: published when its prefetch has landed (right before this item's stores), read by the next
+    // dequant() -- the barrier at the end of the loop body lies between
+    auto landed_and_published = [&]() {
+        loads_landed();
+        if (tid0 < 192) lf_patch[tid0] = raw.llf;
+    };
     int it_no = 0;
 #pragma unroll 1
     for (;;) {
@@ -671,7 +691,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         const Item nn = item_of<P>(a, gi + G);
         load_recs<T, NG>(a, nn, tid, rc);
         STAMP3(3);
-        do_passes<BIG>(a, cur, tid, img, it_no, loads_landed);
+        do_passes<BIG>(a, cur, tid, img, it_no, landed_and_published);
         if (nxt.type < 0) break;
         cur = nxt;
         nxt = nn;
@@ -706,7 +726,7 @@ __device__ __forceinline__ void llf_one(const Wg3Args& a, const Wg3Seg& sg, int 
     const int c = rr / (DSH * DSW), k = rr % (DSH * DSW);
     const v4i rec = ((cv4ip)a.blocks)[sg.first_block + b];
     const int cy = (int)((uint32_t)rec.x & 0xffffu), cx = (int)((uint32_t)rec.x >> 16);
-    const float v = llf_coeff3<DSH, DSW>(a.f.lut, a.f.lf[c] + (int64_t)cy * a.f.bw + cx, a.f.bw, k / DSW, k % DSW);
+    const float v = llf_coeff3<DSH, DSW>(a.f.lut, a.f.lf[c] + (int64_t)cy * a.f.bw + cx, a.f.bw, k / DSW, k % DSW, kLlfScale3);
     (c == 0 ? l0 : c == 1 ? l1 : l2)[(int64_t)(cy + k / DSW) * a.f.bw + cx + k % DSW] = v;
 }
 
@@ -797,6 +817,8 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.total_items = 0;
     a.img_floats = 0;
     a.items = nullptr;
+    static const bool llf_in_item = !(getenv("JXL_WG3_LLF_IN_ITEM") && atoi(getenv("JXL_WG3_LLF_IN_ITEM")) == 0);
+    a.llf_in_item = llf_in_item ? 1 : 0;
     static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
     for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
@@ -917,7 +939,8 @@ int64_t wg3_llf_count(const Wg3Args& a) {
     return n;
 }
 
-size_t wg3_lds_bytes(const Wg3Args& a) { return sizeof(float) * ((size_t)a.img_floats + 3 * 64); }
+// block images + dequantisation table [3][64] + finalizeLLF tables (cosine LUT 70 + 2, LLF scale 32, LF patches 192)
+size_t wg3_lds_bytes(const Wg3Args& a) { return sizeof(float) * ((size_t)a.img_floats + 3 * 64 + 104 + 192); }
 
 // batch forms: dev_args[0..n_frames) in device memory; max_llf = the largest wg3_llf_count, grid_x workgroups per frame,
 // lds = the largest wg3_lds_bytes among the frames
@@ -947,7 +970,7 @@ void launch_idct_wg3(const Wg3Args& a, bool big, int grid_cap, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idct_wg3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set = true;
     }
-    const size_t lds = sizeof(float) * ((size_t)a.img_floats + 3 * 64);
+    const size_t lds = wg3_lds_bytes(a);
     const int grid = std::max(1, std::min(a.total_items, grid_cap));
     if (big) hipLaunchKernelGGL(k_idct_wg3<true>, dim3(grid), dim3(WG3_BIG_T), lds, s, a);
     else hipLaunchKernelGGL(k_idct_wg3<false>, dim3(grid), dim3(256), lds, s, a);
