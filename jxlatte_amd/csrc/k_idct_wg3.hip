@@ -272,20 +272,38 @@ __device__ __forceinline__ float llf_coeff3(const float* __restrict__ lut_all, c
 // ---- work items ---------------------------------------------------------------------------------------------------
 // uniform description of one item (all scalar)
 struct Item {
-    int type;   // TransformType.type; -1: none
-    int first;  // first block record
-    int nb;     // blocks of the item
+    int type;      // TransformType.type; -1: none
+    int first;     // first block record
+    int nb;        // blocks of the item
+    uint32_t geo;  // run-time geometry of the type for the type-generic prefetch (wg3_geo)
+    int wo[3];     // offsets of the type's three weight matrices (DevFrame::woffs of its parameter index)
 };
+
+// geometry word of a type: bits 0-2 log2(W / 4), 4-7 log2(H * W / 4) (4-sample groups per block), 8-10 log2 of the LLF
+// coefficients per block and channel (H / 8 * W / 8), 12-13 log2(W / 8), 15 TransformType.flip() (tall or square), 16-23 the
+// parameter index. The item list carries it (r3), so that the prefetch of an item starts from ONE scalar load instead of a
+// chain of dependent table look-ups and five run-time integer divisions.
+__host__ __device__ inline uint32_t wg3_geo(int type) {
+    const int H = JXL_TT[type].ph, W = JXL_TT[type].pw;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+    return (uint32_t)lg(W / 4) | (uint32_t)lg(H * W / 4) << 4 | (uint32_t)lg((H / 8) * (W / 8)) << 8 | (uint32_t)lg(W / 8) << 12 |
+           (H >= W ? 1u << 15 : 0u) | (uint32_t)JXL_TT[type].param_index << 16;
+}
 
 template <int P>
 __device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
-    Item it{-1, 0, 0};
+    Item it{-1, 0, 0, 0u, {0, 0, 0}};
     if (gi >= a.total_items) return it;
     if (a.items) {  // explicit list (uniform index: scalar loads)
         const auto* w = (const __attribute__((address_space(4))) int*)a.items + 4 * gi;
         it.type = w[0];
         it.first = w[1];
         it.nb = w[2];
+        it.geo = (uint32_t)w[3];
+        const int pi3 = (int)((it.geo >> 16) & 0xffu) * 3;
+        it.wo[0] = a.f.woffs[pi3];
+        it.wo[1] = a.f.woffs[pi3 + 1];
+        it.wo[2] = a.f.woffs[pi3 + 2];
         return it;
     }
     int k = 0;
@@ -296,8 +314,17 @@ __device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
     it.type = sg.type;
     it.first = sg.first_block + li * NB;
     it.nb = min(NB, sg.n_blocks - li * NB);
+    it.geo = wg3_geo(sg.type);
+    const int pi3 = (int)JXL_TT[sg.type].param_index * 3;
+    it.wo[0] = a.f.woffs[pi3];
+    it.wo[1] = a.f.woffs[pi3 + 1];
+    it.wo[2] = a.f.woffs[pi3 + 2];
     return it;
 }
+
+// lane t's LLF coefficient of an item: block t / (3 A), channel and position from the remainder (A = LLF coefficients per
+// block and channel = 1 << lgA, a power of two: only the division by 3 is one, by multiplication)
+__device__ __forceinline__ int llf_lane_block(int tid, int lgA) { return (int)(((uint32_t)tid * 0xAAABu) >> 17) >> lgA; }
 
 // what a lane holds of an item between its prefetch and its dequantisation
 template <int NG, int WS>
@@ -320,9 +347,7 @@ struct Recs {
 
 template <int T, int NG>
 __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int tid, Recs<NG>& rc) {
-    const int H = JXL_TT[it.type < 0 ? 0 : it.type].ph, W = JXL_TT[it.type < 0 ? 0 : it.type].pw;
-    const int lgGPB = __builtin_ctz(H) + __builtin_ctz(W) - 2;
-    const int per_b = 3 * (H >> 3) * (W >> 3);
+    const int lgGPB = (int)((it.geo >> 4) & 15u), lgA = (int)((it.geo >> 8) & 7u);
 #pragma unroll
     for (int j = 0; j < NG; j++) {
         rc.gx[j] = rc.gz[j] = 0;
@@ -338,7 +363,7 @@ __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int 
         }
     }
     rc.lx = 0;
-    const int bl = tid / per_b;
+    const int bl = llf_lane_block(tid, lgA);
     if (it.type >= 0 && bl < it.nb) rc.lx = ((const __attribute__((address_space(4))) int*)a.blocks)[4 * (it.first + bl)];
 }
 
@@ -348,11 +373,9 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     const DevFrame& f = a.f;
     raw.ok = 0;
     raw.llf = 0.0f;
-    const int H = JXL_TT[it.type < 0 ? 0 : it.type].ph, W = JXL_TT[it.type < 0 ? 0 : it.type].pw;
-    const int lgW4 = __builtin_ctz(W) - 2, lgGPB = __builtin_ctz(H) + lgW4;
-    const int PI = JXL_TT[it.type < 0 ? 0 : it.type].param_index;
-    const float* wtab = (H >= W ? f.weights_t : f.weights);  // TransformType.flip() for METHOD_DCT: tall or square
-    const float* wt[3] = {wtab + f.woffs[PI * 3], wtab + f.woffs[PI * 3 + 1], wtab + f.woffs[PI * 3 + 2]};
+    const int lgW4 = (int)(it.geo & 7u), lgGPB = (int)((it.geo >> 4) & 15u);
+    const float* wtab = ((it.geo >> 15) & 1u) ? f.weights_t : f.weights;  // TransformType.flip() for METHOD_DCT: tall or square
+    const float* wt[3] = {wtab + it.wo[0], wtab + it.wo[1], wtab + it.wo[2]};
 #pragma unroll
     for (int j = 0; j < NG; j++) {
         const int g = tid + T * j;
@@ -387,11 +410,11 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     // finalizeLLF input: lane t < nb * PER_B holds LF sample (c, y, x) = t % PER_B of block t / PER_B (for an 8x8 block that IS
     // its LLF coefficient); the lanes exchange them through the LDS patch table and dequant() transforms them (r3: this was a
     // kernel of its own in front of the launch, k_llf_wg3 -- 9 us + a dependent launch on every frame's critical path)
-    const int dsh = H >> 3, dsw = W >> 3, per_b = 3 * dsh * dsw;
-    const int bl = tid / per_b;
+    const int lgA = (int)((it.geo >> 8) & 7u), lgDSW = (int)((it.geo >> 12) & 3u);
+    const int bl = llf_lane_block(tid, lgA);
     if (it.type >= 0 && bl < it.nb) {
-        const int rr = tid - bl * per_b, c = rr / (dsh * dsw), k = rr - c * (dsh * dsw);
-        const int ky = k / dsw, kx = k - ky * dsw;
+        const int rr = tid - ((bl * 3) << lgA), c = rr >> lgA, k = rr & ((1 << lgA) - 1);
+        const int ky = k >> lgDSW, kx = k & ((1 << lgDSW) - 1);
         const int cy = (int)((uint32_t)rc.lx & 0xffffu), cx = (int)((uint32_t)rc.lx >> 16);
         raw.llf = (a.llf_in_item ? f.lf[c] : f.llf[c])[(int64_t)(cy + ky) * f.bw + cx + kx];
     }
@@ -919,7 +942,7 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
         }
     }
     for (const Rec* r : lst) {
-        out.push_back(r->type); out.push_back(r->first); out.push_back(r->nb); out.push_back(0);
+        out.push_back(r->type); out.push_back(r->first); out.push_back(r->nb); out.push_back((int)wg3_geo(r->type));
     }
 }
 
