@@ -116,7 +116,14 @@ __device__ __forceinline__ float fp_tf_pq_tab(float f, const float4* __restrict_
         const float t = f - xm;
         return sg.x + __builtin_fmaf(t, __builtin_fmaf(t, sg.w, sg.z), sg.y);
     }
-    return fp_tf_pq(f);
+    // Outside the table. The two cases that are COMMON in images get their value directly, so that a wave with an out-of-gamut
+    // (negative) or a black sample does not run the ~110 f64 operations of the general form (r3: the synthetic 8K PQ frames
+    // have a negative linear sample in nearly every wave -- the "table" kernel executed the f64 form for all of them):
+    //   f < 0, -inf, +inf, NaN: Math.pow(negative, 0.159...) is NaN (inf: inf / inf) and stays NaN to the end;
+    //   f = +-0: pow = 0, so the result is (float)pow(0.8359375, 78.84375) = 0x354436E8.
+    if ((b & 0x7FFFFFFFu) == 0u) return __builtin_bit_cast(float, 0x354436E8u);
+    if (b >= 0x7F800000u) return __builtin_nanf("");  // sign bit set (and not -0), +inf, NaN
+    return fp_tf_pq(f);  // (0, 2^-40) and [4, inf)
 }
 
 // TF_SRGB.fromLinearF (TransferFunction.java:39-44)

@@ -143,3 +143,16 @@ def test_pq_table_within_one_ulp_of_the_reference_form():
     ref = np.power((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375).astype(np.float32)
     du = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
     assert int(du.max()) <= 1 and float((du != 0).mean()) < 0.02
+
+
+def test_pq_of_zero_constant_in_the_header():
+    """fp_tf_pq_tab returns PQ(+-0) = (float)pow(0.8359375, 78.84375) as a literal (the common out-of-table input besides negative
+    samples): the literal in csrc/jxl_fastpow.h is that float, by libm, by long double and by the oracle's transfer()"""
+    import re
+    from oracle import pyoracle as orc
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jxlatte_amd", "csrc", "jxl_fastpow.h")).read()
+    lit = int(re.search(r"== 0u\) return __builtin_bit_cast\(float, (0x[0-9A-Fa-f]+)u\)", src).group(1), 16)
+    assert lit == int(np.float32(np.power(0.8359375, 78.84375)).view(np.uint32))
+    assert lit == int(np.float32(np.power(np.longdouble(0.8359375), np.longdouble(78.84375))).view(np.uint32))
+    z = orc.transfer(np.array([0.0, -0.0], np.float32), 1)
+    assert int(z[0].view(np.uint32)) == lit and int(z[1].view(np.uint32)) == lit
