@@ -25,7 +25,10 @@
 //     k_idct.hip (lut[n-1][N-1-k] == (-1)^n lut[n-1][k] bit for bit), the three channels interleaved so that one scalar
 //     load of the LUT slice feeds 18 (36) packed operations, four steps per loop trip with the next trip's LUT slices and
 //     LDS samples requested ahead;
-//   * finalizeLLF runs as a small kernel of its own before (k_llf_wg3: one lane per LLF coefficient into the llf planes).
+//   * finalizeLLF runs inside the item (r3): the lane that holds LLF coefficient (c, ky, kx) of a block prefetches LF sample
+//     (c, y, x) of its dctSelect-sized patch, the lanes exchange the patches through a small LDS table and dequant() forms
+//     forwardDCT2D x llfScale there (llf_coeff3). Until r3 a kernel of its own in front of the launch (k_llf_wg3, still
+//     selectable with JXL_WG3_LLF_IN_ITEM=0): 9-13 us and a dependent launch on every frame's critical path.
 // Bit-exactness: every sum keeps the reference's order, multiplies and adds are separate IEEE f32 operations.
 #include "jxl_internal.h"
 #include <cstdio>
@@ -334,7 +337,7 @@ struct Raw {
                            // item a block has at most 256 groups, so both groups of a lane sit at the same place of their blocks
     float kx[NG], kb[NG];  // CfL factors of the group's 64x64 tile (0 where the reference's cache reads 0)
     float hfm[NG];         // (float)hfMultiplier of the group's block
-    float llf;             // lanes < NLLF: one LLF coefficient of the item (finalizeLLF, from the llf planes)
+    float llf;             // lanes < NLLF: one LF sample of the item's blocks (llf_in_item; else the LLF coefficient from the llf planes)
     uint32_t ok;           // bit j: group j belongs to a block of the item
 };
 
