@@ -104,3 +104,49 @@ def test_weights_layout():
     assert np.all(np.isfinite(w)) and np.all(w > 0)
     # DCT8 luma DC weight = 1 / 560
     assert w[offs[1]] == np.float32(1.0) / np.float32(560.0)
+
+
+def test_java_bridge_packs_every_params_field():
+    """integration/jni/GpuFrameBridge.packParams writes jxl_vardct_params field by field (all members 4 bytes wide): the number
+    of values it puts equals the struct's size in words (no JDK here: the Java source is checked as text)"""
+    import ctypes
+    import re
+    from jxlatte_amd import abi
+    src = open(os.path.join(ROOT, "integration", "jni", "GpuFrameBridge.java")).read()
+    body = src[src.index("private static ByteBuffer packParams"):src.index("p.flip();")]
+    # loops: "for (int X = 0; X < N; X++)" applies to the single statement on the next line
+    n = 0
+    mult = 1
+    for line in body.splitlines():
+        code = line.split("//")[0]
+        m = re.search(r"for \(int \w+ = 0; \w+ < ([0-9 +]+); \w+\+\+\)", code)
+        puts = len(re.findall(r"\.put(?:Int|Float)\(", code))
+        if m and not puts:
+            mult = sum(int(t) for t in m.group(1).split("+"))
+            continue
+        n += puts * mult
+        if puts:
+            mult = 1
+    assert n * 4 == ctypes.sizeof(abi.VarDCTParams), (n, ctypes.sizeof(abi.VarDCTParams))
+
+
+def test_gpu_patch_script_anchors_match_the_reference():
+    """tools/patch_reference_for_gpu.sh: its two text patches land in the reference's Frame.java (skipped where the reference
+    checkout is absent, e.g. on the GPU box); the Java build itself needs a JDK and has never run here"""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = "/root/reference/java/com/traneptora/jxlatte/frame/Frame.java"
+    if not os.path.exists(ref) or not shutil.which("perl"):
+        pytest.skip("reference checkout or perl absent")
+    script = open(os.path.join(ROOT, "tools", "patch_reference_for_gpu.sh")).read()
+    sed = re.search(r"^sed -i ('s/\^ +passGroup\.invertVarDCT.*') \"\$F\"$", script, re.M).group(1)
+    perl = re.search(r"^perl -0pi -e ('.*') \"\$F\"$", script, re.M).group(1)
+    with tempfile.TemporaryDirectory() as t:
+        f = os.path.join(t, "Frame.java")
+        shutil.copy(ref, f)
+        subprocess.run("sed -i %s %s && perl -0pi -e %s %s" % (sed, f, perl, f), shell=True, check=True)
+        out = open(f).read()
+    assert out.count("if (!gpuFrame) passGroup.invertVarDCT(buffers, prev);") == 1
+    assert out.count("GpuFrameBridge.invertVarDCT(this, buffers, passGroups, lfGroups, numPasses, numGroups);") == 1
+    assert out.index("GpuFrameBridge.enabled(this)") < out.index("if (!gpuFrame)")
