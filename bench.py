@@ -676,7 +676,7 @@ def end_to_end_leg(_lib, abi, host, synth, frame, device, npx):
         c.close()
 
 
-def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "6")), frames_per_ctx=6):
+def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "12")), frames_per_ctx=8):
     import threading
     lib = _lib.load()
     coeff16 = [np.ascontiguousarray(a, np.int16) for a in d["coeff"]]
