@@ -156,6 +156,7 @@ struct jxl_ctx {
     // 10 = k_llf_wg3, 11 / 12 = k_idct_wg3<false / true> (Wg3Args blocks in batch_wg3_args; grid_x of 10 = lanes)
     struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };
     DevBuf batch_wg3_args;
+    bool coeff16_resident = false;  // stage16 holds the whole frame's committed int16 planes and nothing was put since (JXL_WG3_I16)
     void* h_map16 = nullptr;   // page-locked frame-sized int16 planes handed to the caller (jxl_vardct_map_coeffs_i16)
     size_t h_map16_bytes = 0;
     bool map16_valid = false;
@@ -889,6 +890,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     c->tables_dirty = true;
     c->frame_open = true;
     c->map16_valid = false;
+    c->coeff16_resident = false;
     c->ev_runs = 0;
     c->result[0] = c->result[1] = c->result[2] = nullptr;
     return JXL_OK;
@@ -1066,6 +1068,7 @@ jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const i
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    c->coeff16_resident = false;
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
     const int gy = group / grs, gx = group % grs;  // Frame.getGroupLocation (Frame.java:883)
@@ -1093,6 +1096,7 @@ jxl_status jxl_vardct_put_group_i16(jxl_ctx* c, int32_t pass, int32_t group, con
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    c->coeff16_resident = false;
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
     const int gy = group / grs, gx = group % grs;
@@ -1168,6 +1172,7 @@ jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* c) {
                            Wc, Hc, 0);
         off += (bytes + 255) & ~(size_t)255;
     }
+    c->coeff16_resident = !c->sub;
     return JXL_OK;
 }
 
@@ -1248,6 +1253,14 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 if (tl.cls >= 2) {
                     wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
                     if (c->wg3_item_count[tl.cls - 2] == wn[tl.cls - 2]) wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
+                    static const bool wg3_i16 = getenv("JXL_WG3_I16") && atoi(getenv("JXL_WG3_I16")) != 0;
+                    if (wg3_i16 && c->coeff16_resident) {  // experiment: the prefetch reads the committed int16 planes
+                        size_t off = 0;
+                        for (int ch = 0; ch < 3; ch++) {
+                            wa[tl.cls - 2].coeff16[ch] = reinterpret_cast<const int16_t*>(static_cast<const char*>(c->stage16.p) + off);
+                            off += ((size_t)c->W * c->H * sizeof(int16_t) + 255) & ~(size_t)255;
+                        }
+                    }
                     all.insert(all.end(), tl.segs.begin(), tl.segs.end());
                 }
             if (!all.empty()) {

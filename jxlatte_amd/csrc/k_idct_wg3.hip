@@ -43,6 +43,7 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) float* cfloatp;
 typedef const __attribute__((address_space(4))) v2f* cv2fp;
@@ -397,8 +398,16 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             raw.hfm[j] = (float)rc.gw[j];
             const int py = cy * 8 + n, px = cx * 8 + x4;
             const int64_t off = (int64_t)py * f.width + px;
+            if (a.coeff16[0]) {  // (uniform) 8 bytes per group and channel, widened here
 #pragma unroll
-            for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const v4i*>(f.coeff[c] + off);
+                for (int c = 0; c < 3; c++) {
+                    const v2i pk = *reinterpret_cast<const v2i*>(a.coeff16[c] + off);
+                    raw.q[j][c] = v4i{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const v4i*>(f.coeff[c] + off);
+            }
             // chromaFromLuma factors of the tile this group lies in (4 consecutive x from a multiple of 4 never cross a
             // 64-px boundary), honouring the reference's per-group cache order (DevBlock::cfl_zero)
             const int ty = py >> 6, tx = px >> 6;
@@ -845,6 +854,7 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.items = nullptr;
     static const bool llf_in_item = !(getenv("JXL_WG3_LLF_IN_ITEM") && atoi(getenv("JXL_WG3_LLF_IN_ITEM")) == 0);
     a.llf_in_item = llf_in_item ? 1 : 0;
+    a.coeff16[0] = a.coeff16[1] = a.coeff16[2] = nullptr;
     static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
     for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
