@@ -1358,6 +1358,9 @@ __device__ __forceinline__ void special_wg_body(const DevFrame& f, const DevBloc
 
 __global__ __launch_bounds__(256) void k_idct_special_wg(const DevFrame f, const DevBlock* __restrict__ blocks,
                                                          const WorkItem* __restrict__ items, float* o0, float* o1, float* o2) {
+#ifdef JXL_IDCT_PRIO
+    __builtin_amdgcn_s_setprio(JXL_IDCT_PRIO);
+#endif
     special_wg_body(f, blocks, items[blockIdx.x], o0, o1, o2);
 }
 

@@ -661,6 +661,9 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     const int tid0 = threadIdx.x;
     const int G = (int)gridDim.x;
     int gi = (int)blockIdx.x;
+#ifdef JXL_IDCT_PRIO
+    __builtin_amdgcn_s_setprio(JXL_IDCT_PRIO);
+#endif
     Item cur = item_of<P>(a, gi);
     if (cur.type < 0) return;
     STAMP3_LIFE(0, __builtin_amdgcn_s_memtime());
