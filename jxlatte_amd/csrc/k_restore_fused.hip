@@ -148,6 +148,15 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                 dist[py * 4 + px][3] = vc[py + 1][px];  // tap (+1,0)
             }
     } else {
+    // 13-tap iteration: the four taps on the patch's own row -- (0,-1), (0,1), (0,-2), (0,2) -- are pair distances that two pixels of
+    // the 4x1 patch share (dist(p, p + t) and dist(p + t, p) are the same terms in the same order): 5 + 6 chains instead of 16.
+    // The other eight taps pair a pixel with one of another row, i.e. of another thread's patch.
+    constexpr bool HROW = ITER == 0 && CHAINS && PH == 1;
+    float h1[5], h2[6];
+#pragma unroll
+    for (int j = 0; j < 5; j++) h1[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) h2[j] = 0.0f;
     // channels one after the other (not interleaved by the scheduler): keeps the live set under 128 VGPRs
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {
@@ -167,6 +176,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                 const int cy = py + R, cx = px + R;  // centre inside nb
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
+                    if (HROW && TY[t] == 0) continue;  // through h1 / h2 below
                     if (ITER == 2) {  // epfDistance2 (:657-669): single pixel
                         dist[py * 4 + px][t] =
                             dist[py * 4 + px][t] + adiff<NW>(nb, cy * NW + cx, (cy + TY[t]) * NW + cx + TX[t], sc);
@@ -179,6 +189,32 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                         }
                     }
                 }
+            }
+        if (HROW) {
+            constexpr int cy = R;
+#pragma unroll
+            for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const int u = (cy + QY[q]) * NW + (j - 1 + R) + QX[q];
+                    h1[j] = h1[j] + adiff<NW>(nb, u, u + 1, sc);
+                }
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const int u = (cy + QY[q]) * NW + (j - 2 + R) + QX[q];
+                    h2[j] = h2[j] + adiff<NW>(nb, u, u + 2, sc);
+                }
+        }
+    }
+    if (HROW) {
+#pragma unroll
+        for (int px = 0; px < 4; px++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (TY[t] != 0) continue;
+                dist[px][t] = TX[t] == -1 ? h1[px] : TX[t] == 1 ? h1[px + 1] : TX[t] == -2 ? h2[px] : h2[px + 2];
             }
     }
     }
