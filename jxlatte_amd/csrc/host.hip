@@ -1317,7 +1317,10 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             // item -- 28 us alone on the device, 58-72 us beside the other class's workgroups -- so it goes first on the side
             // stream and the 8x8 special kernel (24 us) behind it, not in front of it
             static const bool big_first = !(getenv("JXL_WG3_BIG_FIRST") && atoi(getenv("JXL_WG3_BIG_FIRST")) == 0);
-            const bool big_early = big_first && plan != 1 && !any_llf && wn[1] > 0;
+            // experiment (JXL_WG3_BIG_AFTER=1): the 64-point launch on the MAIN stream behind the <= 32-point launch, so that no CU
+            // ever holds two workgroups of each (4 x 128 registers per lane: no room for a restoration workgroup of another frame)
+            static const bool big_after = getenv("JXL_WG3_BIG_AFTER") && atoi(getenv("JXL_WG3_BIG_AFTER")) != 0;
+            const bool big_early = big_first && !big_after && plan != 1 && !any_llf && wn[1] > 0;
             if (big_early) {
                 launch_idct_wg3(wa[1], true, wg3_grid_big, side);
                 launches++;
@@ -1349,7 +1352,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 launches++;
             }
             if (plan != 1 && wn[1] > 0 && !big_early) {
-                launch_idct_wg3(wa[1], true, wg3_grid_big, s_big);
+                launch_idct_wg3(wa[1], true, wg3_grid_big, big_after ? s : s_big);
                 launches++;
             }
             for (const auto& tl : c->type_launches)  // nothing today: every class 0 / 1 type of such a frame is handled above
