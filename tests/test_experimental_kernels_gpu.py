@@ -33,10 +33,14 @@ sys.exit(1 if bad else 0)
 """ % ROOT
 
 
-@pytest.mark.parametrize("switch", ["JXL_IDCT_WAVE", "JXL_RESTORE_STREAM"])
+@pytest.mark.parametrize("switch", ["JXL_IDCT_WAVE", "JXL_RESTORE_STREAM", "JXL_WG3_LLF_IN_ITEM=0", "JXL_WG3_BALANCE=0", "JXL_WG3_BIG_FIRST=0",
+                                    "JXL_WG3_BIG_AFTER", "JXL_WG3_SPATIAL=0"])
 def test_switched_kernel_is_bit_exact(switch):
+    """the experimental kernels, and the launch-plan / item-order switches DESIGN.md and profiles/r3_experiments.md name (each a
+    path that was the default at some point): same bits as the oracle"""
     env = dict(os.environ)
-    env[switch] = "1"
+    name, _, val = switch.partition("=")
+    env[name] = val or "1"
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RESULT 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
