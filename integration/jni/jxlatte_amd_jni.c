@@ -56,7 +56,7 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_destroy(JNI
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_beginFrame(JNIEnv* e, jobject self, jobject params) {
     jxl_ctx* c = ctx_of(e, self);
     jxl_vardct_params p;
-    if ((size_t)(*e)->GetDirectBufferCapacity(e, params) < sizeof p) {
+    if (!params || (*e)->GetDirectBufferCapacity(e, params) < (jlong)sizeof p) {
         rethrow(e, c, JXL_ERR_INVALID_ARGUMENT);
         return;
     }
