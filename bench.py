@@ -683,7 +683,7 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
     ctxs = [_lib.Context(device) for _ in range(n_ctx)]
     pouts = [host.PinnedArray(lib, ref_out.shape, ref_out.dtype) for _ in range(n_ctx)]
     start = threading.Barrier(n_ctx + 1)
-    errs, same = [], [True] * n_ctx
+    errs, same, t_end = [], [True] * n_ctx, [0.0] * n_ctx
 
     def worker(i):
         c = ctxs[i]
@@ -705,6 +705,7 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
             start.wait()
             for _ in range(frames_per_ctx):
                 one_frame()
+            t_end[i] = time.perf_counter()  # (the comparison below is the bench's own check, not the boundary's work)
             same[i] = bool(np.array_equal(pouts[i].array, ref_out))
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e)[:200])
@@ -721,7 +722,7 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
         a = time.perf_counter()
         for t in th:
             t.join()
-        wall = time.perf_counter() - a
+        wall = (max(t_end) if min(t_end) > 0.0 else time.perf_counter()) - a
     finally:
         for t in th:
             t.join()

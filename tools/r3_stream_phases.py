@@ -3,6 +3,9 @@
 import ctypes as C, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("R3_WITH_TORCH"):  # bench.py's process has torch loaded (its streaming leg reads lower: is it torch?)
+    import torch
+    torch.zeros(1, device="cuda")
 from jxlatte_amd import _lib, abi, host, synth
 
 W, H = 3840, 2160
