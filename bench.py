@@ -50,6 +50,7 @@ def parse(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=4, help="distinct synthetic frames generated per rank (the rest reuse them)")
     ap.add_argument("--mix", default="default")
+    ap.add_argument("--stream-groups", type=int, default=0, help="experiment: the frames' contexts share G main streams (0: one per frame)")
     ap.add_argument("--size", default="", help="WxH override of the synthetic VarDCT frame size (diagnostics; named in config.workload)")
     ap.add_argument("--epf-iters", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0, help="0 = one HIP stream per frame context (default); 1 = all frames of a rank share one stream")
@@ -205,6 +206,8 @@ def main():
         c = _lib.Context(local_rank)
         if args.streams == 1 and ctxs:
             c.call("jxl_ctx_set_stream", ctxs[0].stream)
+        elif args.stream_groups and i >= args.stream_groups:  # experiment: contexts i, i + G, ... launch on ONE main stream
+            c.call("jxl_ctx_set_stream", ctxs[i % args.stream_groups].stream)
         ctxs.append(c)
         if args.workload == "jxlfile":
             from jxlatte_amd.decoder import load_vardct_frame
