@@ -14,6 +14,7 @@
 #include <atomic>
 #include <thread>
 #include <vector>
+#include <limits>
 
 using namespace jxl;
 
@@ -126,6 +127,7 @@ struct jxl_ctx {
     std::vector<LfJob> lf_jobs;  // integer LF images to dequantise + smooth on the device (row f1)
     DevBuf lfq_tmp[3];
     DevBuf pq_tab;  // PQ segment table (jxl_fastpow.h), uploaded at context creation
+    DevBuf srgb8_tab;  // sRGB -> 8-bit threshold table (fp_srgb8), uploaded at context creation
     // resident colour planes between decodeFrame and the colour transform (jxl_planes_*): dense [rp_h][rp_w] floats
     DevBuf rp[3], rp_tmp[3], rp_noise[3];
     int rp_h = 0, rp_w = 0;
@@ -672,7 +674,47 @@ void build_pq_table(float* out) {
 }
 }  // namespace jxl
 
+namespace jxl {
+// The reference's composite for an 8-bit sRGB sample: TF_SRGB.fromLinearF (TransferFunction.java:39-44) then
+// ImageBuffer.castToIntWithMax(255) (ImageBuffer.java:129-147), in the reference's own operations (this file is built with
+// -ffp-contract=off; the double pow is the host libm's, as in the oracle)
+static int srgb8_ref(float f) {
+    const volatile float t = f < 0.00313066844250063f ? f * 12.92f : 1.055f * (float)std::pow((double)f, 0.4166666666666667) + -0.055f;
+    const volatile float v = t * 255.0f + 0.5f;
+    if (v != v) return 0;
+    if (v >= 255.0f) return 255;
+    if (v <= 0.0f) return 0;
+    return (int)v;
+}
+// fp_srgb8's table (jxl_fastpow.h): per segment {base level, up to three thresholds (+inf: none)}
+bool build_srgb8_table(float* out) {
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int i = 0; i < (127 - 118) * 128; i++) {
+        const uint32_t b0 = ((uint32_t)i + (118u << 7)) << 16, b1 = b0 + 0x10000u;  // the segment's floats: bits in [b0, b1)
+        auto at = [](uint32_t b) { float f; memcpy(&f, &b, 4); return srgb8_ref(f); };
+        const int base = at(b0), last = at(b1 - 1);
+        if (last < base || last - base > 3) return false;
+        out[4 * i] = (float)base;
+        for (int k = 1; k <= 3; k++) {
+            float thr = inf;
+            if (base + k <= last) {  // smallest bit pattern in the segment whose level is >= base + k (levels do not decrease)
+                uint32_t lo = b0, hi = b1 - 1;  // at(lo) < base + k <= at(hi)
+                while (hi - lo > 1) {
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    if (at(mid) >= base + k) hi = mid; else lo = mid;
+                }
+                memcpy(&thr, &hi, 4);
+            }
+            out[4 * i + k] = thr;
+        }
+    }
+    return true;
+}
+}  // namespace jxl
+
 extern "C" void jxl_debug_pq_table(float* out) { jxl::build_pq_table(out); }  // CPU tests: the table without a device
+extern "C" int jxl_debug_srgb8_table(float* out) { return jxl::build_srgb8_table(out) ? 0 : -1; }
+extern "C" int jxl_debug_srgb8_ref(float f) { return jxl::srgb8_ref(f); }
 
 namespace {
 int out_elem_size(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 2 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 1 : 4; }
@@ -745,6 +787,21 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
             }
         }
     }
+    {
+        static std::vector<float> st;  // the same for every context of the process
+        static bool st_ok = false;
+        if (st.empty()) {
+            st.resize(kSrgb8TableFloats);
+            st_ok = build_srgb8_table(st.data());
+        }
+        if (st_ok && !getenv("JXL_SRGB8_F64")) {  // experiment knob: keep the double-precision form for 8-bit sRGB output too
+            if (!c->srgb8_tab.ensure(sizeof(float) * st.size()) ||
+                hipMemcpy(c->srgb8_tab.p, st.data(), sizeof(float) * st.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                jxl_ctx_destroy(c);
+                return fail(nullptr, JXL_ERR_DEVICE, "cannot upload the sRGB table");
+            }
+        }
+    }
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
@@ -782,6 +839,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     }
     for (int i = 0; i < 3; i++) c->hfm_sub[i].release();
     c->pq_tab.release();
+    c->srgb8_tab.release();
     for (int i = 0; i < 3; i++) { c->rp[i].release(); c->rp_tmp[i].release(); c->rp_noise[i].release(); }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
@@ -1447,6 +1505,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         rp.xybp = make_xyb(p.opsin_matrix, p.opsin_bias, p.cbrt_opsin_bias, p.intensity_target);
         rp.global_scale_f = p.global_scale_f;
         rp.pq_tab = p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>();  // _EXACT: the double-precision form
+        rp.srgb8_tab = c->srgb8_tab.as<float>();
         memcpy(rp.sharp_lut, p.epf_sharp_lut, sizeof rp.sharp_lut);
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
@@ -1495,7 +1554,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             const bool il = out_interleaved(p.out_format);
             for (int i = 0; i < 3; i++) {
                 launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : p.transfer, maxv,
-                                c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>());
+                                c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>());
                 c->result[i] = c->outbuf[i].p;
                 launches++;
             }
@@ -2062,7 +2121,7 @@ jxl_status jxl_stage_transfer(jxl_ctx* c, const float* in, int64_t n, int32_t tr
     int32_t* dout = t.up<int32_t>(nullptr, (size_t)n);
     if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
     launch_transfer(di, n, transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : transfer, max_value, dout, 4, c->stream, 1, 0,
-                    transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>());
+                    transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>());
     if ((st = finish(c))) return st;
     HIP_TRY(c, hipMemcpy(max_value > 0 ? (void*)out_i : (void*)out_f, dout, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return JXL_OK;

@@ -126,6 +126,33 @@ __device__ __forceinline__ float fp_tf_pq_tab(float f, const float4* __restrict_
     return fp_tf_pq(f);  // (0, 2^-40) and [4, inf)
 }
 
+// ---- sRGB + 8-bit quantisation as a table of thresholds (r3) ---------------------------------------------------------------
+// The composite the reference applies to a sample on its way into an 8-bit PNG -- TF_SRGB.fromLinearF (TransferFunction.java:39-44:
+// one double pow, a float multiply and add) and ImageBuffer.castToIntWithMax(255) ((int)(t * 255 + 0.5f), clamped,
+// ImageBuffer.java:129-147) -- is a non-decreasing function float -> {0..255}. So it is fully described by the smallest float
+// that reaches each level: the host finds those 255 thresholds by bisection over float bit patterns with the reference's own
+// formula (build_srgb8_table, host.hip) and files them by segment (the floats of [2^-9, 1) with equal bits >> 16: 9 binades x
+// 128; a segment holds at most 3 thresholds). The device looks up base level + up to three comparisons instead of ~110 f64
+// operations: the same integer for EVERY input by construction (checked over all 2^32 inputs: tools/pq_sweep.py --srgb8).
+// Below 2^-9 the reference is on its linear branch (f * 12.92f): the same float operations are done here directly.
+constexpr int kSrgb8ExpLo = 118;  // biased exponent of 2^-9
+constexpr int kSrgb8Segs = (127 - kSrgb8ExpLo) * 128;
+
+__device__ __forceinline__ int fp_srgb8(float f, const float4* __restrict__ tab) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    const uint32_t idx = (b >> 16) - ((uint32_t)kSrgb8ExpLo << 7);  // negative, tiny, >= 1, NaN: outside
+    if (idx < (uint32_t)kSrgb8Segs) {
+        const float4 sg = tab[idx];
+        return (int)sg.x + (f >= sg.y ? 1 : 0) + (f >= sg.z ? 1 : 0) + (f >= sg.w ? 1 : 0);
+    }
+    if (f >= 1.0f) return 255;  // 1.055f * pow - 0.055f >= 1 - 2^-24: 255.49998 and up, clamped
+    if (!(f == f)) return 0;    // (int)NaN
+    const float v = (f * 12.92f) * 255.0f + 0.5f;  // linear branch (f < 0.0031306684), Java (int) cast, clamp
+    if (v >= 255.0f) return 255;
+    if (!(v >= 0.0f)) return 0;  // negative (and -inf)
+    return (int)v;
+}
+
 // TF_SRGB.fromLinearF (TransferFunction.java:39-44)
 __device__ __forceinline__ float fp_tf_srgb(float f) {
     if (f < 0.00313066844250063f) return f * 12.92f;

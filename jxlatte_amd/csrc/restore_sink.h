@@ -52,6 +52,21 @@ __device__ __forceinline__ void sink_store(const FusedArgs& a, uint32_t g, float
         for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
         return;
     }
+#ifndef JXL_EXACT_POW
+    if (a.p.transfer == JXL_TRANSFER_SRGB && a.p.max_value == 255 && a.p.srgb8_tab) {  // sRGB + 8-bit quantisation: threshold table
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int32_t q = fp_srgb8(v[c], reinterpret_cast<const float4*>(a.p.srgb8_tab));
+            if (a.p.interleaved) {
+                if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
+                else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
+            } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+            else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
+            else ((int32_t*)a.out[c])[g] = q;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float t = v[c];

@@ -156,3 +156,48 @@ def test_pq_of_zero_constant_in_the_header():
     assert lit == int(np.float32(np.power(np.longdouble(0.8359375), np.longdouble(78.84375))).view(np.uint32))
     z = orc.transfer(np.array([0.0, -0.0], np.float32), 1)
     assert int(z[0].view(np.uint32)) == lit and int(z[1].view(np.uint32)) == lit
+
+
+def _srgb8_lookup(x, tab):
+    """numpy restatement of fp_srgb8 (csrc/jxl_fastpow.h) on the table build_srgb8_table makes"""
+    b = x.view(np.uint32)
+    idx = (b >> np.uint32(16)).astype(np.int64) - (118 << 7)
+    inside = (idx >= 0) & (idx < 9 * 128)
+    q = np.zeros(x.shape, np.int64)
+    sg = tab[np.where(inside, idx, 0)]
+    with np.errstate(invalid="ignore", over="ignore"):
+        qi = sg[:, 0].astype(np.int64) + (x >= sg[:, 1]) + (x >= sg[:, 2]) + (x >= sg[:, 3])
+        v = (x * np.float32(12.92)) * np.float32(255.0) + np.float32(0.5)
+        lin = np.where(v >= 255.0, 255, np.where(v >= 0.0, np.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0).astype(np.int64), 0))
+    q = np.where(inside, qi, np.where(x >= 1.0, 255, np.where(np.isnan(x), 0, lin)))
+    return q
+
+
+def test_srgb8_threshold_table_equals_the_reference_composite():
+    """sRGB + castToIntWithMax(255) as thresholds: the table the library builds, looked up as the device does, gives the oracle's
+    integer for every threshold's neighbourhood, the special values and 4 million random floats (all 2^32 inputs: tools/pq_sweep.py
+    --srgb8 on the GPU box, profiles/r3_srgb8_sweep.txt)"""
+    import ctypes as C
+    from jxlatte_amd import _lib
+    from oracle import pyoracle as orc
+    lib = _lib.load()
+    tab = np.zeros(9 * 128 * 4, np.float32)
+    lib.jxl_debug_srgb8_table.restype = C.c_int
+    lib.jxl_debug_srgb8_table.argtypes = [C.c_void_p]
+    assert lib.jxl_debug_srgb8_table(tab.ctypes.data) == 0
+    tab = tab.reshape(-1, 4)
+    assert tab[0, 0] >= 6 and tab[-1, 0] <= 255 and np.all(np.diff(tab[:, 0]) >= 0)
+    thr = tab[:, 1:][np.isfinite(tab[:, 1:])]
+    assert thr.size == int(tab[-1, 0] + np.isfinite(tab[-1, 1:]).sum() - tab[0, 0])  # one threshold per level step of [2^-9, 1)
+    tb = thr.view(np.uint32).astype(np.int64)
+    near = np.concatenate([tb + d for d in (-2, -1, 0, 1, 2)]).astype(np.uint32).view(np.float32)
+    rng = np.random.default_rng(5)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 2.0 ** -9, np.nextafter(np.float32(2.0 ** -9), np.float32(0)), 0.0031306684, 0.00313066844250063,
+                        0.0031306685, 0.5, 0.99999994, 1.0, 1.0000001, 2.0, 1e30, np.inf, -np.inf, np.nan, -1.0, -1e-4, 1e-4, 1.95e-3], np.float32)
+    x = np.concatenate([near, special, rng.random(2000000).astype(np.float32), (10.0 ** rng.uniform(-12, 1, 1000000)).astype(np.float32),
+                        -(10.0 ** rng.uniform(-12, 1, 200000)).astype(np.float32),
+                        rng.integers(0, 2 ** 32, 800000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    exp = orc.transfer(x, 2, 255)
+    got = _srgb8_lookup(x, tab)
+    bad = np.flatnonzero(got != exp)
+    assert bad.size == 0, (x[bad[:5]], got[bad[:5]], exp[bad[:5]])

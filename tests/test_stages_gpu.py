@@ -144,6 +144,15 @@ def test_transfer_special_values_and_range(ctx, orc, tf):
     assert d.max() <= 1 and (d != 0).mean() < (1e-2 if tf == abi.TRANSFER_PQ else 1e-4), (int(d.max()), float((d != 0).mean()))
 
 
+def test_srgb_8bit_output_is_exact(ctx, orc):
+    """sRGB + 8-bit quantisation runs through the threshold table (fp_srgb8): the oracle's integer for every input, not a tolerance"""
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.random(1000000), 10.0 ** rng.uniform(-10, 0.5, 500000), -(10.0 ** rng.uniform(-10, 0, 100000)),
+                        [0.0, -0.0, 1.0, 0.99999994, 1.0000001, 0.0031306684, 0.0031306685, 2.0 ** -9, 1e30, np.inf, -np.inf, np.nan]]).astype(F)
+    x = np.concatenate([x, rng.integers(0, 2 ** 32, 500000, dtype=np.uint64).astype(np.uint32).view(F)])
+    assert np.array_equal(host.transfer(ctx, x, abi.TRANSFER_SRGB, 255), orc.transfer(x, abi.TRANSFER_SRGB, 255))
+
+
 def test_quantise_java_int_cast_semantics(ctx, orc):
     x = np.array([-1e30, -0.2, -0.0, 0.0, 0.49, 0.5, 1.0, 7.0, 1e30, np.inf, -np.inf, np.nan], F)
     for maxv in (255, 65535):
