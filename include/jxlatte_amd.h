@@ -51,11 +51,12 @@ typedef int32_t jxl_status;
                             * quantisation are one look-up in a table of the composite's 255 thresholds: the reference's integer for
                             * every float input (all 2^32 checked); float / 16-bit output evaluate the double pow on the device */
 /* Tolerance of the PQ entries against the reference's (float)Math.pow(double) form. JXL_TRANSFER_PQ evaluates a table of
- * quadratic segments (jxl_fastpow.h): over ALL 2^32 float inputs 99.96 % identical, the rest off by exactly 1 ulp, none worse
- * (profiles/r2_pq_sweep.txt) -- so a quantised u8 / u16 sample can differ by 1 LSB where the float lands on a rounding
- * boundary. JXL_TRANSFER_PQ_EXACT evaluates the same two pow() in double precision on the device (3x the instructions; the
- * pre-round-2 form): use it where the samples must be the reference's bit for bit. Both are accepted by jxl_vardct_params.transfer
- * and jxl_stage_transfer. */
+ * quadratic segments (jxl_fastpow.h): as FLOAT output over ALL 2^32 inputs 99.96 % identical, the rest off by exactly 1 ulp, none
+ * worse (profiles/r3_pq_sweep.txt). With 16-bit output (JXL_OUT_U16 / RGB16, max 65535) the quantised sample is the reference's
+ * integer for EVERY input (r3: the table value is settled against the composite's 65 535 thresholds, profiles/r3_pq16_sweep.txt);
+ * an 8-bit PQ sample can differ by 1 LSB where the float lands on a rounding boundary. JXL_TRANSFER_PQ_EXACT evaluates the two
+ * pow() in double precision on the device (3x the instructions; the pre-round-2 form). Both are accepted by
+ * jxl_vardct_params.transfer and jxl_stage_transfer. */
 #define JXL_TRANSFER_PQ_EXACT 3
 #define JXL_OUT_F32 0       /* float planes */
 #define JXL_OUT_U16 1       /* ImageBuffer.castToIntWithMax(65535), ImageBuffer.java:129-147 */

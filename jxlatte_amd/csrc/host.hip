@@ -14,6 +14,7 @@
 #include <atomic>
 #include <thread>
 #include <vector>
+#include <mutex>
 #include <limits>
 
 using namespace jxl;
@@ -128,6 +129,7 @@ struct jxl_ctx {
     DevBuf lfq_tmp[3];
     DevBuf pq_tab;  // PQ segment table (jxl_fastpow.h), uploaded at context creation
     DevBuf srgb8_tab;  // sRGB -> 8-bit threshold table (fp_srgb8), uploaded at context creation
+    DevBuf pq16_thr;   // PQ -> 16-bit thresholds (fp_pq16), built and uploaded on the first PQ frame / stage with 16-bit output
     // resident colour planes between decodeFrame and the colour transform (jxl_planes_*): dense [rp_h][rp_w] floats
     DevBuf rp[3], rp_tmp[3], rp_noise[3];
     int rp_h = 0, rp_w = 0;
@@ -712,7 +714,45 @@ bool build_srgb8_table(float* out) {
 }
 }  // namespace jxl
 
+namespace jxl {
+// TF_PQ.fromLinear (TransferFunction.java:83-87) then ImageBuffer.castToIntWithMax(65535), in the reference's own operations
+static int pq16_ref(float f) {
+    const double d = std::pow((double)f, 0.159423828125);
+    const volatile float t = (float)std::pow((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375);
+    const volatile float v = t * 65535.0f + 0.5f;
+    if (v != v) return 0;
+    if (v >= 65535.0f) return 65535;
+    if (v <= 0.0f) return 0;
+    return (int)v;
+}
+// thr[k], k = 1..65535: the smallest float whose level is >= k (bisection over the bit patterns of [+0, 1.0f]; the level does
+// not decrease with the input); thr[0] = -inf, thr[65536] = +inf. ~4 M pow calls: on 8 threads, once per process, on first use.
+void build_pq16_thresholds(float* out) {
+    const float inf = std::numeric_limits<float>::infinity();
+    out[0] = -inf;
+    out[65536] = inf;
+    const uint32_t one = 0x3F800000u;
+    auto at = [](uint32_t b) { float f; memcpy(&f, &b, 4); return pq16_ref(f); };
+    auto work = [&](int t, int nt) {
+        for (int k = 1 + t; k <= 65535; k += nt) {
+            uint32_t lo = 0u, hi = one;  // at(lo) = 0 < k <= 65535 = at(hi)
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (at(mid) >= k) hi = mid; else lo = mid;
+            }
+            memcpy(&out[k], &hi, 4);
+        }
+    };
+    const int nt = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t, nt);
+    work(0, nt);
+    for (auto& x : th) x.join();
+}
+}  // namespace jxl
+
 extern "C" void jxl_debug_pq_table(float* out) { jxl::build_pq_table(out); }  // CPU tests: the table without a device
+extern "C" void jxl_debug_pq16_thresholds(float* out) { jxl::build_pq16_thresholds(out); }
 extern "C" int jxl_debug_srgb8_table(float* out) { return jxl::build_srgb8_table(out) ? 0 : -1; }
 extern "C" int jxl_debug_srgb8_ref(float f) { return jxl::srgb8_ref(f); }
 
@@ -720,6 +760,28 @@ namespace {
 int out_elem_size(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 2 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 1 : 4; }
 int out_max_value(int fmt) { return (fmt == JXL_OUT_U16 || fmt == JXL_OUT_RGB16) ? 65535 : (fmt == JXL_OUT_U8 || fmt == JXL_OUT_RGB8) ? 255 : 0; }
 bool out_interleaved(int fmt) { return fmt == JXL_OUT_RGB8 || fmt == JXL_OUT_RGB16; }
+
+// device thresholds of PQ -> 16 bit for this context, or null (other transfer / range, JXL_PQ16_F64=1, allocation failure: the
+// caller then quantises the float result). Built once per process on first use (~4 M pow calls on 8 host threads).
+const float* pq16_thresholds_for(jxl_ctx* c, int transfer, int max_value) {
+    if (transfer != JXL_TRANSFER_PQ || max_value != 65535 || !c->pq_tab.p) return nullptr;
+    static const bool off = getenv("JXL_PQ16_F64") != nullptr;
+    if (off) return nullptr;
+    if (c->pq16_thr.p) return c->pq16_thr.as<float>();
+    static std::once_flag once;
+    static std::vector<float> thr;
+    std::call_once(once, [] {
+        thr.resize(65537);
+        build_pq16_thresholds(thr.data());
+    });
+    if (!c->pq16_thr.ensure(sizeof(float) * thr.size()) ||
+        hipMemcpy(c->pq16_thr.p, thr.data(), sizeof(float) * thr.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        c->pq16_thr.release();
+        return nullptr;
+    }
+    return c->pq16_thr.as<float>();
+}
 
 }  // namespace
 
@@ -840,6 +902,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     for (int i = 0; i < 3; i++) c->hfm_sub[i].release();
     c->pq_tab.release();
     c->srgb8_tab.release();
+    c->pq16_thr.release();
     for (int i = 0; i < 3; i++) { c->rp[i].release(); c->rp_tmp[i].release(); c->rp_noise[i].release(); }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
@@ -1506,6 +1569,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         rp.global_scale_f = p.global_scale_f;
         rp.pq_tab = p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>();  // _EXACT: the double-precision form
         rp.srgb8_tab = c->srgb8_tab.as<float>();
+        rp.pq16_thr = do_out ? pq16_thresholds_for(c, p.transfer, out_max_value(p.out_format)) : nullptr;
         memcpy(rp.sharp_lut, p.epf_sharp_lut, sizeof rp.sharp_lut);
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
@@ -1554,7 +1618,8 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             const bool il = out_interleaved(p.out_format);
             for (int i = 0; i < 3; i++) {
                 launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : p.transfer, maxv,
-                                c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>());
+                                c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>(),
+                                pq16_thresholds_for(c, p.transfer, maxv));
                 c->result[i] = c->outbuf[i].p;
                 launches++;
             }
@@ -2121,7 +2186,8 @@ jxl_status jxl_stage_transfer(jxl_ctx* c, const float* in, int64_t n, int32_t tr
     int32_t* dout = t.up<int32_t>(nullptr, (size_t)n);
     if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
     launch_transfer(di, n, transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : transfer, max_value, dout, 4, c->stream, 1, 0,
-                    transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>());
+                    transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>(),
+                    pq16_thresholds_for(c, transfer, max_value));
     if ((st = finish(c))) return st;
     HIP_TRY(c, hipMemcpy(max_value > 0 ? (void*)out_i : (void*)out_f, dout, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return JXL_OK;

@@ -126,6 +126,30 @@ __device__ __forceinline__ float fp_tf_pq_tab(float f, const float4* __restrict_
     return fp_tf_pq(f);  // (0, 2^-40) and [4, inf)
 }
 
+// ---- PQ + 16-bit quantisation, exact (r3) -------------------------------------------------------------------------------------
+// TF_PQ.fromLinear followed by ImageBuffer.castToIntWithMax(65535) is a non-decreasing function float -> {0..65535}: thr[k] is
+// the smallest float that reaches level k (host: build_pq16_thresholds, bisection over bit patterns with the reference's own
+// formula; thr[0] = -inf, thr[65536] = +inf). The table form above gives the level to within +-1 (its float is within 1 ulp,
+// i.e. 0.004 levels, of the reference's), and ONE comparison against the two neighbouring thresholds settles it: the
+// reference's integer for every input (all 2^32 checked: tools/pq_sweep.py --pq16), where the float route alone differs by one
+// level for 1 input in ~10^4.
+__device__ __forceinline__ int fp_pq16(float f, const float4* __restrict__ tab, const float* __restrict__ thr) {
+    if (!(f >= thr[1])) return 0;      // below the first threshold, negative, zero, NaN
+    if (f >= thr[65535]) return f == __builtin_inff() ? 0 : 65535;  // (+inf: pow gives inf / inf = NaN, and (int)NaN is 0)
+    const float t = fp_tf_pq_tab(f, tab);  // f is inside (0, 1): the table's range
+    const float v = t * 65535.0f + 0.5f;
+    int q = (int)v;
+    // t is within 1 ulp of the reference's float (<= 0.004 levels), the two float roundings of v add <= 0.004: unless v lies
+    // within 0.01 of an integer, q IS the reference's level and the thresholds need not be read (2 % of the samples do)
+    const float fr = v - (float)q;
+    if (fr < 0.01f || fr > 0.99f) {
+        q = q < 1 ? 1 : q > 65534 ? 65534 : q;
+        const float lo = thr[q], hi = thr[q + 1];
+        q += (f >= hi ? 1 : 0) - (f < lo ? 1 : 0);
+    }
+    return q;
+}
+
 // ---- sRGB + 8-bit quantisation as a table of thresholds (r3) ---------------------------------------------------------------
 // The composite the reference applies to a sample on its way into an 8-bit PNG -- TF_SRGB.fromLinearF (TransferFunction.java:39-44:
 // one double pow, a float multiply and add) and ImageBuffer.castToIntWithMax(255) ((int)(t * 255 + 0.5f), clamped,

@@ -201,3 +201,22 @@ def test_srgb8_threshold_table_equals_the_reference_composite():
     got = _srgb8_lookup(x, tab)
     bad = np.flatnonzero(got != exp)
     assert bad.size == 0, (x[bad[:5]], got[bad[:5]], exp[bad[:5]])
+
+
+def test_pq16_thresholds_describe_the_reference_composite():
+    """PQ + castToIntWithMax(65535) as thresholds (build_pq16_thresholds): strictly increasing, and for every level k the threshold
+    is the first float that reaches it -- thr[k] gives k, the float just below gives k - 1 (oracle's transfer())"""
+    import ctypes as C
+    from jxlatte_amd import _lib
+    from oracle import pyoracle as orc
+    lib = _lib.load()
+    thr = np.zeros(65537, np.float32)
+    lib.jxl_debug_pq16_thresholds.restype = None
+    lib.jxl_debug_pq16_thresholds.argtypes = [C.c_void_p]
+    lib.jxl_debug_pq16_thresholds(thr.ctypes.data)
+    assert thr[0] == -np.inf and thr[65536] == np.inf
+    t = thr[1:65536]
+    assert np.all(np.diff(t.view(np.uint32).astype(np.int64)) > 0) and t[0] > 0 and t[-1] <= 1.0
+    assert np.array_equal(orc.transfer(t, 1, 65535), np.arange(1, 65536))
+    below = (t.view(np.uint32) - np.uint32(1)).view(np.float32)
+    assert np.array_equal(orc.transfer(below, 1, 65535), np.arange(0, 65535))

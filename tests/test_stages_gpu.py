@@ -144,6 +144,15 @@ def test_transfer_special_values_and_range(ctx, orc, tf):
     assert d.max() <= 1 and (d != 0).mean() < (1e-2 if tf == abi.TRANSFER_PQ else 1e-4), (int(d.max()), float((d != 0).mean()))
 
 
+def test_pq_16bit_output_is_exact(ctx, orc):
+    """PQ + 16-bit quantisation: table value + one look at the composite's thresholds (fp_pq16): the oracle's code value for every input"""
+    rng = np.random.default_rng(22)
+    x = np.concatenate([rng.random(1000000), 10.0 ** rng.uniform(-12, 0.5, 500000), -(10.0 ** rng.uniform(-10, 0, 50000)),
+                        [0.0, -0.0, 1.0, 0.99999994, 1.0000001, 3.9, 4.0, 1e30, 3e38, np.inf, -np.inf, np.nan, 1e-45, 9e-13]]).astype(F)
+    x = np.concatenate([x, rng.integers(0, 2 ** 32, 500000, dtype=np.uint64).astype(np.uint32).view(F)])
+    assert np.array_equal(host.transfer(ctx, x, abi.TRANSFER_PQ, 65535), orc.transfer(x, abi.TRANSFER_PQ, 65535))
+
+
 def test_srgb_8bit_output_is_exact(ctx, orc):
     """sRGB + 8-bit quantisation runs through the threshold table (fp_srgb8): the oracle's integer for every input, not a tolerance"""
     rng = np.random.default_rng(21)
@@ -225,8 +234,7 @@ def test_u16_pq_output_path(ctx, orc):
     got = host.Frame.from_synth(ctx, frame).decodeFrame()
     exp = orc.vardct_frame(frame)
     assert got.dtype == np.uint16
-    d = np.abs(got.astype(np.int64) - exp.astype(np.int64))
-    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    assert np.array_equal(got, exp)  # (r3: exact -- fp_pq16)
 
 
 @pytest.mark.parametrize("iters", [1, 2, 3])

@@ -21,31 +21,34 @@ ap.add_argument("--chunk-log2", type=int, default=26)
 ap.add_argument("--out", default="")
 ap.add_argument("--limit", type=int, default=0, help="only the first N chunks (smoke)")
 ap.add_argument("--srgb8", action="store_true", help="instead: sRGB + 8-bit quantisation (the threshold table fp_srgb8) against the oracle, exact equality")
+ap.add_argument("--pq16", action="store_true", help="instead: PQ + 16-bit quantisation (fp_pq16: table + threshold correction) against the oracle, exact equality")
 args = ap.parse_args()
-if args.srgb8:
+if args.srgb8 or args.pq16:
+    TF, MAXV, NAME = (abi.TRANSFER_SRGB, 255, "sRGB + castToIntWithMax(255), device (threshold table)") if args.srgb8 else \
+                     (abi.TRANSFER_PQ, 65535, "PQ + castToIntWithMax(65535), device (table + thresholds)")
     ctx = _lib.Context(0)
     n = 1 << args.chunk_log2
     chunks = (1 << 32) // n if not args.limit else min((1 << 32) // n, args.limit)
     bad, first = 0, None
-    hist = np.zeros(256, np.int64)
+    hist = np.zeros(MAXV + 1, np.int64)
     t0 = time.time()
     for k in range(chunks):
         bits = (np.arange(n, dtype=np.uint64) + np.uint64(k) * np.uint64(n)).astype(np.uint32)
         x = bits.view(np.float32)
-        got = host.transfer(ctx, x, abi.TRANSFER_SRGB, 255)
-        exp = orc.transfer(x, abi.TRANSFER_SRGB, 255)
+        got = host.transfer(ctx, x, TF, MAXV)
+        exp = orc.transfer(x, TF, MAXV)
         ne = np.flatnonzero(got != exp)
         bad += ne.size
         if ne.size and first is None:
             first = (int(bits[ne[0]]), int(got[ne[0]]), int(exp[ne[0]]))
-        hist += np.bincount(exp.astype(np.int64), minlength=256)[:256]
+        hist += np.bincount(exp.astype(np.int64), minlength=MAXV + 1)[:MAXV + 1]
         if k % 8 == 7:
             print("chunk %d / %d  mismatches %d  (%.0f s)" % (k + 1, chunks, bad, time.time() - t0), flush=True)
-    lines = ["sRGB + castToIntWithMax(255), device (threshold table) vs oracle, all float32 inputs in %d chunks of 2^%d (%s)"
-             % (chunks, args.chunk_log2, _lib.load().jxl_version().decode()),
+    lines = ["%s vs oracle, all float32 inputs in %d chunks of 2^%d (%s)"
+             % (NAME, chunks, args.chunk_log2, _lib.load().jxl_version().decode()),
              "inputs compared: %d" % (chunks * n), "mismatches: %d" % bad,
              "first mismatch (input bits, device, oracle): %s" % (first,),
-             "inputs per level: 0 -> %d, 255 -> %d, 1..254 -> %d" % (hist[0], hist[255], hist[1:255].sum()),
+             "inputs per level: 0 -> %d, %d -> %d, between -> %d; levels never produced: %d" % (hist[0], MAXV, hist[MAXV], hist[1:MAXV].sum(), int((hist == 0).sum())),
              "wall time %.0f s" % (time.time() - t0)]
     print("\n".join(lines))
     if args.out:
