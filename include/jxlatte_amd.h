@@ -47,9 +47,9 @@ typedef int32_t jxl_status;
 /* output stage selector (PNGWriter ctor: tf = hdr ? PQ : sRGB; bit depth 8/16) */
 #define JXL_TRANSFER_NONE 0 /* stop after invertXYB: linear float */
 #define JXL_TRANSFER_PQ   1 /* TransferFunction.TF_PQ.fromLinear, TransferFunction.java:83-87 */
-#define JXL_TRANSFER_SRGB 2 /* TransferFunction.TF_SRGB.fromLinearF, :39-44. With 8-bit output (JXL_OUT_U8 / RGB8, max 255) transfer and
-                            * quantisation are one look-up in a table of the composite's 255 thresholds: the reference's integer for
-                            * every float input (all 2^32 checked); float / 16-bit output evaluate the double pow on the device */
+#define JXL_TRANSFER_SRGB 2 /* TransferFunction.TF_SRGB.fromLinearF, :39-44. With 8-bit or 16-bit output (max 255 / 65535) transfer and
+                            * quantisation go through tables of the composite's thresholds: the reference's integer for every float
+                            * input (all 2^32 checked for both); float output evaluates the double pow on the device */
 /* Tolerance of the PQ entries against the reference's (float)Math.pow(double) form. JXL_TRANSFER_PQ evaluates a table of
  * quadratic segments (jxl_fastpow.h): as FLOAT output over ALL 2^32 inputs 99.96 % identical, the rest off by exactly 1 ulp, none
  * worse (profiles/r3_pq_sweep.txt). With 16-bit output (JXL_OUT_U16 / RGB16, max 65535) the quantised sample is the reference's

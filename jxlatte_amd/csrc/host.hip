@@ -129,6 +129,7 @@ struct jxl_ctx {
     DevBuf lfq_tmp[3];
     DevBuf pq_tab;  // PQ segment table (jxl_fastpow.h), uploaded at context creation
     DevBuf srgb8_tab;  // sRGB -> 8-bit threshold table (fp_srgb8), uploaded at context creation
+    DevBuf srgb16_tab; // sRGB -> 16 bit: segments + thresholds (fp_srgb16), built and uploaded on first use
     DevBuf pq16_thr;   // PQ -> 16-bit thresholds (fp_pq16), built and uploaded on the first PQ frame / stage with 16-bit output
     // resident colour planes between decodeFrame and the colour transform (jxl_planes_*): dense [rp_h][rp_w] floats
     DevBuf rp[3], rp_tmp[3], rp_noise[3];
@@ -749,10 +750,58 @@ void build_pq16_thresholds(float* out) {
     work(0, nt);
     for (auto& x : th) x.join();
 }
+// TF_SRGB.fromLinearF then ImageBuffer.castToIntWithMax(65535), in the reference's own operations
+static int srgb16_ref(float f) {
+    const volatile float t = f < 0.00313066844250063f ? f * 12.92f : 1.055f * (float)std::pow((double)f, 0.4166666666666667) + -0.055f;
+    const volatile float v = t * 65535.0f + 0.5f;
+    if (v != v) return 0;
+    if (v >= 65535.0f) return 65535;
+    if (v <= 0.0f) return 0;
+    return (int)v;
+}
+// fp_srgb16's tables: quadratic segments of c1 x^(1/2.4) - c0 over [2^-9, 1) (as build_pq_table), then the 65 537 thresholds
+void build_srgb16_table(float* out) {
+    const long double cn = 0.86602540378443864676L, c1 = (long double)1.055f, c0 = (long double)0.055f;
+    auto T = [&](long double x) { return c1 * powl(x, 1.0L / 2.4L) - c0; };
+    for (int i = 0; i < (127 - 118) * 128; i++) {
+        const uint32_t b0 = ((uint32_t)i + (118u << 7)) << 16, bm = b0 | 0x00008000u;
+        float x0f, xmf;
+        memcpy(&x0f, &b0, 4);
+        memcpy(&xmf, &bm, 4);
+        const long double xm = xmf, h = (long double)xmf - (long double)x0f, tn = h * cn;
+        const long double y0 = T(xm), yp = T(xm + tn), ym = T(xm - tn);
+        const float a0hi = (float)y0;
+        out[4 * i + 0] = a0hi;
+        out[4 * i + 1] = (float)(y0 - (long double)a0hi);
+        out[4 * i + 2] = (float)((yp - ym) / (2.0L * tn));
+        out[4 * i + 3] = (float)((yp + ym - 2.0L * y0) / (2.0L * tn * tn));
+    }
+    float* thr = out + kSrgb8TableFloats;
+    const float inf = std::numeric_limits<float>::infinity();
+    thr[0] = -inf;
+    thr[65536] = inf;
+    auto at = [](uint32_t b) { float f; memcpy(&f, &b, 4); return srgb16_ref(f); };
+    auto work = [&](int t, int nt) {
+        for (int k = 1 + t; k <= 65535; k += nt) {
+            uint32_t lo = 0u, hi = 0x3F800000u;  // at(+0) = 0 < k <= 65535 = at(1.0f)
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (at(mid) >= k) hi = mid; else lo = mid;
+            }
+            memcpy(&thr[k], &hi, 4);
+        }
+    };
+    const int nt = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work, t, nt);
+    work(0, nt);
+    for (auto& x : th) x.join();
+}
 }  // namespace jxl
 
 extern "C" void jxl_debug_pq_table(float* out) { jxl::build_pq_table(out); }  // CPU tests: the table without a device
 extern "C" void jxl_debug_pq16_thresholds(float* out) { jxl::build_pq16_thresholds(out); }
+extern "C" void jxl_debug_srgb16_table(float* out) { jxl::build_srgb16_table(out); }
 extern "C" int jxl_debug_srgb8_table(float* out) { return jxl::build_srgb8_table(out) ? 0 : -1; }
 extern "C" int jxl_debug_srgb8_ref(float f) { return jxl::srgb8_ref(f); }
 
@@ -778,9 +827,31 @@ const float* pq16_thresholds_for(jxl_ctx* c, int transfer, int max_value) {
         hipMemcpy(c->pq16_thr.p, thr.data(), sizeof(float) * thr.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
         c->pq16_thr.release();
+    c->srgb16_tab.release();
         return nullptr;
     }
     return c->pq16_thr.as<float>();
+}
+
+// the same for sRGB -> 16 bit (fp_srgb16): segments + thresholds, or null (JXL_SRGB16_F64=1: the double-precision form)
+const float* srgb16_table_for(jxl_ctx* c, int transfer, int max_value) {
+    if (transfer != JXL_TRANSFER_SRGB || max_value != 65535) return nullptr;
+    static const bool off = getenv("JXL_SRGB16_F64") != nullptr;
+    if (off) return nullptr;
+    if (c->srgb16_tab.p) return c->srgb16_tab.as<float>();
+    static std::once_flag once;
+    static std::vector<float> tab;
+    std::call_once(once, [] {
+        tab.resize((size_t)kSrgb8TableFloats + 65537);
+        build_srgb16_table(tab.data());
+    });
+    if (!c->srgb16_tab.ensure(sizeof(float) * tab.size()) ||
+        hipMemcpy(c->srgb16_tab.p, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        c->srgb16_tab.release();
+        return nullptr;
+    }
+    return c->srgb16_tab.as<float>();
 }
 
 }  // namespace
@@ -1570,6 +1641,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         rp.pq_tab = p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>();  // _EXACT: the double-precision form
         rp.srgb8_tab = c->srgb8_tab.as<float>();
         rp.pq16_thr = do_out ? pq16_thresholds_for(c, p.transfer, out_max_value(p.out_format)) : nullptr;
+        rp.srgb16_tab = do_out ? srgb16_table_for(c, p.transfer, out_max_value(p.out_format)) : nullptr;
         memcpy(rp.sharp_lut, p.epf_sharp_lut, sizeof rp.sharp_lut);
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
@@ -1619,7 +1691,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             for (int i = 0; i < 3; i++) {
                 launch_transfer(cur[i], (int64_t)c->W * c->H, p.transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : p.transfer, maxv,
                                 c->outbuf[il ? 0 : i].p, es, s, il ? 3 : 1, il ? i : 0, p.transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>(),
-                                pq16_thresholds_for(c, p.transfer, maxv));
+                                pq16_thresholds_for(c, p.transfer, maxv), srgb16_table_for(c, p.transfer, maxv));
                 c->result[i] = c->outbuf[i].p;
                 launches++;
             }
@@ -2187,7 +2259,7 @@ jxl_status jxl_stage_transfer(jxl_ctx* c, const float* in, int64_t n, int32_t tr
     if (!di || !dout) return fail(c, JXL_ERR_OOM, "device allocation failed");
     launch_transfer(di, n, transfer == JXL_TRANSFER_PQ_EXACT ? JXL_TRANSFER_PQ : transfer, max_value, dout, 4, c->stream, 1, 0,
                     transfer == JXL_TRANSFER_PQ_EXACT ? nullptr : c->pq_tab.as<float>(), c->srgb8_tab.as<float>(),
-                    pq16_thresholds_for(c, transfer, max_value));
+                    pq16_thresholds_for(c, transfer, max_value), srgb16_table_for(c, transfer, max_value));
     if ((st = finish(c))) return st;
     HIP_TRY(c, hipMemcpy(max_value > 0 ? (void*)out_i : (void*)out_f, dout, 4 * (size_t)n, hipMemcpyDeviceToHost));
     return JXL_OK;

@@ -177,6 +177,32 @@ __device__ __forceinline__ int fp_srgb8(float f, const float4* __restrict__ tab)
     return (int)v;
 }
 
+// ---- sRGB + 16-bit quantisation, exact (r3): the two ideas above combined -------------------------------------------------
+// tab16: quadratic segments of T(x) = c1 x^(1/2.4) - c0 (c1, c0 the reference's float constants) over [2^-9, 1), laid out like
+// the PQ table; thr: the 65 535 thresholds of TF_SRGB.fromLinearF + castToIntWithMax(65535) (build_srgb16_thresholds). The
+// reference rounds three times on the way to its float (pow cast, multiply, add), the table once: the level guess can be off by
+// one where t * 65535 + 0.5 lies within 0.02 of an integer (4 % of the samples), and only those read their two thresholds.
+// Below the branch point the reference's own float operations are done directly.
+__device__ __forceinline__ int fp_srgb16(float f, const float4* __restrict__ tab16, const float* __restrict__ thr) {
+    if (!(f >= thr[1])) return 0;       // below the first threshold, negative, zero, NaN
+    if (f >= thr[65535]) return 65535;  // (+inf too: pow gives inf, (int)inf clamps)
+    if (f < 0.00313066844250063f) return (int)((f * 12.92f) * 65535.0f + 0.5f);  // linear branch: positive, below 2656
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    const float4 sg = tab16[(b >> 16) - ((uint32_t)kSrgb8ExpLo << 7)];  // f in [0.00313, thr[65535]) inside [2^-9, 1)
+    const float xm = __builtin_bit_cast(float, (b & 0xFFFF0000u) | 0x00008000u);
+    const float tt = f - xm;
+    const float t = sg.x + __builtin_fmaf(tt, __builtin_fmaf(tt, sg.w, sg.z), sg.y);
+    const float v = t * 65535.0f + 0.5f;
+    int q = (int)v;
+    const float fr = v - (float)q;
+    if (fr < 0.02f || fr > 0.98f) {
+        q = q < 1 ? 1 : q > 65534 ? 65534 : q;
+        const float lo = thr[q], hi = thr[q + 1];
+        q += (f >= hi ? 1 : 0) - (f < lo ? 1 : 0);
+    }
+    return q;
+}
+
 // TF_SRGB.fromLinearF (TransferFunction.java:39-44)
 __device__ __forceinline__ float fp_tf_srgb(float f) {
     if (f < 0.00313066844250063f) return f * 12.92f;

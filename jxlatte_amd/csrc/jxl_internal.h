@@ -179,13 +179,14 @@ void launch_ycbcr(float* const planes[3], int64_t n, hipStream_t s);
 // pq_tab: the PQ segment table of build_pq_table (device; null: the double-precision form)
 void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s,
                      int out_pitch = 1, int out_off = 0, const float* pq_tab = nullptr, const float* srgb8_tab = nullptr,
-                     const float* pq16_thr = nullptr);
+                     const float* pq16_thr = nullptr, const float* srgb16_tab = nullptr);
 // PQ as a table of quadratic segments (jxl_fastpow.h): kPqTableFloats floats = float4 {a0 hi, a0 lo, a1, a2} per segment
 constexpr int kPqTableFloats = (129 - 87) * 128 * 4;
 void build_pq_table(float* out /* [kPqTableFloats] */);
 constexpr int kSrgb8TableFloats = (127 - 118) * 128 * 4;
 bool build_srgb8_table(float* out /* [kSrgb8TableFloats] */);
-void build_pq16_thresholds(float* out /* [65537] */);  // false: a segment with more than three thresholds (never)
+void build_pq16_thresholds(float* out /* [65537] */);
+void build_srgb16_table(float* out /* [kSrgb8TableFloats + 65537]: segments, then thresholds */);  // false: a segment with more than three thresholds (never)
 // fused restoration + colour tile kernel (Gab -> EPF iters -> XYB -> optional transfer/quantise)
 struct RestoreParams {
     int gab, epf_iters, xyb, transfer, max_value, out_elem;
@@ -198,6 +199,8 @@ struct RestoreParams {
     const float* pq_tab;  // device: PQ segment table (null: double-precision PQ)
     const float* srgb8_tab;  // device: sRGB -> 8-bit threshold table (fp_srgb8; null: double-precision pow + quantise)
     const float* pq16_thr;   // device: the 65537 thresholds of PQ -> 16 bit (fp_pq16; null: table / f64 float result, then quantise)
+    const float* srgb16_tab;  // device: quadratic segments of the sRGB curve over [2^-9, 1) + (at float offset kSrgb8TableFloats) the
+                              // 65537 thresholds of sRGB -> 16 bit (fp_srgb16; null: double-precision pow + quantise)
 };
 // argument block of the fused kernel (one per frame; an array of them for the batched launch)
 struct FusedArgs {

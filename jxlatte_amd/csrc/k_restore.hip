@@ -250,12 +250,18 @@ __device__ __forceinline__ int32_t quantise(float v, int max_value) {
 
 __global__ __launch_bounds__(256) void k_transfer(const float* in, int64_t n, int transfer, int max_value, void* out,
                                                   int out_elem, int out_pitch, int out_off, const float4* pq_tab, const float4* srgb8_tab,
-                                                  const float* pq16_thr) {
+                                                  const float* pq16_thr, const float* srgb16_tab) {
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t o = i * out_pitch + out_off;
 #ifndef JXL_EXACT_POW
         if (transfer == JXL_TRANSFER_PQ && max_value == 65535 && pq_tab && pq16_thr) {  // PQ + 16-bit quantisation, exact
             const int32_t q = fp_pq16(in[i], pq_tab, pq16_thr);
+            if (out_elem == 4) ((int32_t*)out)[o] = q;
+            else ((uint16_t*)out)[o] = (uint16_t)q;
+            continue;
+        }
+        if (transfer == JXL_TRANSFER_SRGB && max_value == 65535 && srgb16_tab) {  // sRGB + 16-bit quantisation, exact
+            const int32_t q = fp_srgb16(in[i], reinterpret_cast<const float4*>(srgb16_tab), srgb16_tab + kSrgb8TableFloats);
             if (out_elem == 4) ((int32_t*)out)[o] = q;
             else ((uint16_t*)out)[o] = (uint16_t)q;
             continue;
@@ -281,12 +287,13 @@ __global__ __launch_bounds__(256) void k_transfer(const float* in, int64_t n, in
 }
 
 void launch_transfer(const float* in, int64_t n, int transfer, int max_value, void* out, int out_elem, hipStream_t s,
-                     int out_pitch, int out_off, const float* pq_tab, const float* srgb8_tab, const float* pq16_thr) {
+                     int out_pitch, int out_off, const float* pq_tab, const float* srgb8_tab, const float* pq16_thr,
+                     const float* srgb16_tab) {
     if (n <= 0) return;
     int grid = (int)((n + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(k_transfer, dim3(grid), dim3(256), 0, s, in, n, transfer, max_value, out, out_elem, out_pitch, out_off,
-                       reinterpret_cast<const float4*>(pq_tab), reinterpret_cast<const float4*>(srgb8_tab), pq16_thr);
+                       reinterpret_cast<const float4*>(pq_tab), reinterpret_cast<const float4*>(srgb8_tab), pq16_thr, srgb16_tab);
 }
 
 }  // namespace jxl

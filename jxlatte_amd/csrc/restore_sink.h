@@ -63,6 +63,16 @@ __device__ __forceinline__ void sink_store(const FusedArgs& a, uint32_t g, float
         }
         return;
     }
+    if (a.p.transfer == JXL_TRANSFER_SRGB && a.p.max_value == 65535 && a.p.srgb16_tab) {  // sRGB + 16-bit quantisation, exact
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int32_t q = fp_srgb16(v[c], reinterpret_cast<const float4*>(a.p.srgb16_tab), a.p.srgb16_tab + kSrgb8TableFloats);
+            if (a.p.interleaved) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
+            else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+            else ((int32_t*)a.out[c])[g] = q;
+        }
+        return;
+    }
     if (a.p.transfer == JXL_TRANSFER_SRGB && a.p.max_value == 255 && a.p.srgb8_tab) {  // sRGB + 8-bit quantisation: threshold table
 #pragma unroll
         for (int c = 0; c < 3; c++) {

@@ -220,3 +220,31 @@ def test_pq16_thresholds_describe_the_reference_composite():
     assert np.array_equal(orc.transfer(t, 1, 65535), np.arange(1, 65536))
     below = (t.view(np.uint32) - np.uint32(1)).view(np.float32)
     assert np.array_equal(orc.transfer(below, 1, 65535), np.arange(0, 65535))
+
+
+def test_srgb16_thresholds_describe_the_reference_composite():
+    """sRGB + castToIntWithMax(65535) as thresholds (build_srgb16_table): strictly increasing; thr[k] gives level k, the float just
+    below gives k - 1 (oracle's transfer()); and the segment table in front of them is the curve to float accuracy"""
+    import ctypes as C
+    from jxlatte_amd import _lib
+    from oracle import pyoracle as orc
+    lib = _lib.load()
+    nseg = 9 * 128 * 4
+    buf = np.zeros(nseg + 65537, np.float32)
+    lib.jxl_debug_srgb16_table.restype = None
+    lib.jxl_debug_srgb16_table.argtypes = [C.c_void_p]
+    lib.jxl_debug_srgb16_table(buf.ctypes.data)
+    thr = buf[nseg:]
+    assert thr[0] == -np.inf and thr[65536] == np.inf
+    t = thr[1:65536]
+    assert np.all(np.diff(t.view(np.uint32).astype(np.int64)) > 0) and t[0] > 0 and t[-1] <= 1.0
+    assert np.array_equal(orc.transfer(t, 2, 65535), np.arange(1, 65536))
+    below = (t.view(np.uint32) - np.uint32(1)).view(np.float32)
+    assert np.array_equal(orc.transfer(below, 2, 65535), np.arange(0, 65535))
+    # the segments: value at each segment midpoint against the oracle's float curve (<= 2 ulp: three roundings against one)
+    seg = buf[:nseg].reshape(-1, 4)
+    mid = ((np.arange(9 * 128, dtype=np.uint32) + np.uint32(118 << 7)) << np.uint32(16) | np.uint32(0x8000)).view(np.float32)
+    ok = mid >= np.float32(0.0031306685)
+    ref = orc.transfer(mid[ok], 2)
+    d = np.abs(seg[ok, 0].view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert d.max() <= 2, d.max()

@@ -153,6 +153,15 @@ def test_pq_16bit_output_is_exact(ctx, orc):
     assert np.array_equal(host.transfer(ctx, x, abi.TRANSFER_PQ, 65535), orc.transfer(x, abi.TRANSFER_PQ, 65535))
 
 
+def test_srgb_16bit_output_is_exact(ctx, orc):
+    """sRGB + 16-bit quantisation: segment table + thresholds (fp_srgb16): the oracle's code value for every input"""
+    rng = np.random.default_rng(23)
+    x = np.concatenate([rng.random(1000000), 10.0 ** rng.uniform(-12, 0.5, 500000), -(10.0 ** rng.uniform(-10, 0, 50000)),
+                        [0.0, -0.0, 1.0, 0.99999994, 1.0000001, 0.0031306684, 0.0031306685, 2.0 ** -9, 1e30, 3e38, np.inf, -np.inf, np.nan, 1e-45]]).astype(F)
+    x = np.concatenate([x, rng.integers(0, 2 ** 32, 500000, dtype=np.uint64).astype(np.uint32).view(F)])
+    assert np.array_equal(host.transfer(ctx, x, abi.TRANSFER_SRGB, 65535), orc.transfer(x, abi.TRANSFER_SRGB, 65535))
+
+
 def test_srgb_8bit_output_is_exact(ctx, orc):
     """sRGB + 8-bit quantisation runs through the threshold table (fp_srgb8): the oracle's integer for every input, not a tolerance"""
     rng = np.random.default_rng(21)
