@@ -54,7 +54,7 @@ typedef int32_t jxl_status;
  * quadratic segments (jxl_fastpow.h): as FLOAT output over ALL 2^32 inputs 99.96 % identical, the rest off by exactly 1 ulp, none
  * worse (profiles/r3_pq_sweep.txt). With 16-bit output (JXL_OUT_U16 / RGB16, max 65535) the quantised sample is the reference's
  * integer for EVERY input (r3: the table value is settled against the composite's 65 535 thresholds, profiles/r3_pq16_sweep.txt);
- * an 8-bit PQ sample can differ by 1 LSB where the float lands on a rounding boundary. JXL_TRANSFER_PQ_EXACT evaluates the two
+ * an 8-bit PQ sample likewise (binary search in its 255 thresholds, profiles/r3_pq8_sweep.txt). JXL_TRANSFER_PQ_EXACT evaluates the two
  * pow() in double precision on the device (3x the instructions; the pre-round-2 form). Both are accepted by
  * jxl_vardct_params.transfer and jxl_stage_transfer. */
 #define JXL_TRANSFER_PQ_EXACT 3

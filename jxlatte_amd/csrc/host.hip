@@ -750,6 +750,31 @@ void build_pq16_thresholds(float* out) {
     work(0, nt);
     for (auto& x : th) x.join();
 }
+// PQ -> 8 bit: thr[1..255] appended to the 16-bit thresholds' buffer (offset 65537: thr8[0] = -inf, thr8[256] = +inf)
+static int pq8_ref(float f) {
+    const double d = std::pow((double)f, 0.159423828125);
+    const volatile float t = (float)std::pow((0.8359375 + 18.8515625 * d) / (1.0 + 18.6875 * d), 78.84375);
+    const volatile float v = t * 255.0f + 0.5f;
+    if (v != v) return 0;
+    if (v >= 255.0f) return 255;
+    if (v <= 0.0f) return 0;
+    return (int)v;
+}
+void build_pq8_thresholds(float* out /* [257] */) {
+    const float inf = std::numeric_limits<float>::infinity();
+    out[0] = -inf;
+    out[256] = inf;
+    auto at = [](uint32_t b) { float f; memcpy(&f, &b, 4); return pq8_ref(f); };
+    for (int k = 1; k <= 255; k++) {
+        uint32_t lo = 0u, hi = 0x3F800000u;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (at(mid) >= k) hi = mid; else lo = mid;
+        }
+        memcpy(&out[k], &hi, 4);
+    }
+}
+
 // TF_SRGB.fromLinearF then ImageBuffer.castToIntWithMax(65535), in the reference's own operations
 static int srgb16_ref(float f) {
     const volatile float t = f < 0.00313066844250063f ? f * 12.92f : 1.055f * (float)std::pow((double)f, 0.4166666666666667) + -0.055f;
@@ -802,6 +827,7 @@ void build_srgb16_table(float* out) {
 extern "C" void jxl_debug_pq_table(float* out) { jxl::build_pq_table(out); }  // CPU tests: the table without a device
 extern "C" void jxl_debug_pq16_thresholds(float* out) { jxl::build_pq16_thresholds(out); }
 extern "C" void jxl_debug_srgb16_table(float* out) { jxl::build_srgb16_table(out); }
+extern "C" void jxl_debug_pq8_thresholds(float* out) { jxl::build_pq8_thresholds(out); }
 extern "C" int jxl_debug_srgb8_table(float* out) { return jxl::build_srgb8_table(out) ? 0 : -1; }
 extern "C" int jxl_debug_srgb8_ref(float f) { return jxl::srgb8_ref(f); }
 
@@ -813,15 +839,16 @@ bool out_interleaved(int fmt) { return fmt == JXL_OUT_RGB8 || fmt == JXL_OUT_RGB
 // device thresholds of PQ -> 16 bit for this context, or null (other transfer / range, JXL_PQ16_F64=1, allocation failure: the
 // caller then quantises the float result). Built once per process on first use (~4 M pow calls on 8 host threads).
 const float* pq16_thresholds_for(jxl_ctx* c, int transfer, int max_value) {
-    if (transfer != JXL_TRANSFER_PQ || max_value != 65535 || !c->pq_tab.p) return nullptr;
+    if (transfer != JXL_TRANSFER_PQ || (max_value != 65535 && max_value != 255) || !c->pq_tab.p) return nullptr;
     static const bool off = getenv("JXL_PQ16_F64") != nullptr;
     if (off) return nullptr;
     if (c->pq16_thr.p) return c->pq16_thr.as<float>();
     static std::once_flag once;
     static std::vector<float> thr;
     std::call_once(once, [] {
-        thr.resize(65537);
+        thr.resize(65537 + 257);
         build_pq16_thresholds(thr.data());
+        build_pq8_thresholds(thr.data() + 65537);
     });
     if (!c->pq16_thr.ensure(sizeof(float) * thr.size()) ||
         hipMemcpy(c->pq16_thr.p, thr.data(), sizeof(float) * thr.size(), hipMemcpyHostToDevice) != hipSuccess) {

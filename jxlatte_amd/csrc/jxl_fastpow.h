@@ -177,6 +177,18 @@ __device__ __forceinline__ int fp_srgb8(float f, const float4* __restrict__ tab)
     return (int)v;
 }
 
+// ---- PQ + 8-bit quantisation, exact (r3): 255 thresholds, binary search (a rare output format: no segment table) -----------------
+// thr[0] = -inf, thr[k] = the smallest float of level k, thr[256] = +inf (build_pq8_thresholds); +inf and NaN give 0 as in the
+// reference (pow(inf) / pow(inf) = NaN, (int)NaN = 0).
+__device__ __forceinline__ int fp_pq8(float f, const float* __restrict__ thr) {
+    if (!(f >= thr[1]) || f == __builtin_inff()) return 0;
+    int q = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1)
+        if (f >= thr[q + step]) q += step;  // q + step <= 255
+    return q;
+}
+
 // ---- sRGB + 16-bit quantisation, exact (r3): the two ideas above combined -------------------------------------------------
 // tab16: quadratic segments of T(x) = c1 x^(1/2.4) - c0 (c1, c0 the reference's float constants) over [2^-9, 1), laid out like
 // the PQ table; thr: the 65 535 thresholds of TF_SRGB.fromLinearF + castToIntWithMax(65535) (build_srgb16_thresholds). The

@@ -186,6 +186,7 @@ void build_pq_table(float* out /* [kPqTableFloats] */);
 constexpr int kSrgb8TableFloats = (127 - 118) * 128 * 4;
 bool build_srgb8_table(float* out /* [kSrgb8TableFloats] */);
 void build_pq16_thresholds(float* out /* [65537] */);
+void build_pq8_thresholds(float* out /* [257] */);
 void build_srgb16_table(float* out /* [kSrgb8TableFloats + 65537]: segments, then thresholds */);  // false: a segment with more than three thresholds (never)
 // fused restoration + colour tile kernel (Gab -> EPF iters -> XYB -> optional transfer/quantise)
 struct RestoreParams {
@@ -198,7 +199,8 @@ struct RestoreParams {
     float sharp_lut[8];
     const float* pq_tab;  // device: PQ segment table (null: double-precision PQ)
     const float* srgb8_tab;  // device: sRGB -> 8-bit threshold table (fp_srgb8; null: double-precision pow + quantise)
-    const float* pq16_thr;   // device: the 65537 thresholds of PQ -> 16 bit (fp_pq16; null: table / f64 float result, then quantise)
+    const float* pq16_thr;   // device: the 65537 thresholds of PQ -> 16 bit (fp_pq16), then the 257 of PQ -> 8 bit (fp_pq8);
+                             // null: table / f64 float result, then quantise
     const float* srgb16_tab;  // device: quadratic segments of the sRGB curve over [2^-9, 1) + (at float offset kSrgb8TableFloats) the
                               // 65537 thresholds of sRGB -> 16 bit (fp_srgb16; null: double-precision pow + quantise)
 };

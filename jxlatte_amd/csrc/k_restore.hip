@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256) void k_transfer(const float* in, int64_t n, in
             else ((uint16_t*)out)[o] = (uint16_t)q;
             continue;
         }
+        if (transfer == JXL_TRANSFER_PQ && max_value == 255 && pq16_thr) {  // PQ + 8-bit quantisation, exact
+            const int32_t q = fp_pq8(in[i], pq16_thr + 65537);
+            if (out_elem == 4) ((int32_t*)out)[o] = q;
+            else if (out_elem == 2) ((uint16_t*)out)[o] = (uint16_t)q;
+            else ((uint8_t*)out)[o] = (uint8_t)q;
+            continue;
+        }
         if (transfer == JXL_TRANSFER_SRGB && max_value == 65535 && srgb16_tab) {  // sRGB + 16-bit quantisation, exact
             const int32_t q = fp_srgb16(in[i], reinterpret_cast<const float4*>(srgb16_tab), srgb16_tab + kSrgb8TableFloats);
             if (out_elem == 4) ((int32_t*)out)[o] = q;

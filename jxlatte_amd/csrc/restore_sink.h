@@ -63,6 +63,19 @@ __device__ __forceinline__ void sink_store(const FusedArgs& a, uint32_t g, float
         }
         return;
     }
+    if (a.p.transfer == JXL_TRANSFER_PQ && a.p.max_value == 255 && a.p.pq16_thr) {  // PQ + 8-bit quantisation, exact
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int32_t q = fp_pq8(v[c], a.p.pq16_thr + 65537);
+            if (a.p.interleaved) {
+                if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
+                else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
+            } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+            else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
+            else ((int32_t*)a.out[c])[g] = q;
+        }
+        return;
+    }
     if (a.p.transfer == JXL_TRANSFER_SRGB && a.p.max_value == 65535 && a.p.srgb16_tab) {  // sRGB + 16-bit quantisation, exact
 #pragma unroll
         for (int c = 0; c < 3; c++) {

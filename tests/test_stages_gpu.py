@@ -153,6 +153,15 @@ def test_pq_16bit_output_is_exact(ctx, orc):
     assert np.array_equal(host.transfer(ctx, x, abi.TRANSFER_PQ, 65535), orc.transfer(x, abi.TRANSFER_PQ, 65535))
 
 
+def test_pq_8bit_output_is_exact(ctx, orc):
+    """PQ + 8-bit quantisation: binary search in the composite's 255 thresholds (fp_pq8)"""
+    rng = np.random.default_rng(24)
+    x = np.concatenate([rng.random(500000), 10.0 ** rng.uniform(-12, 0.5, 300000), -(10.0 ** rng.uniform(-10, 0, 50000)),
+                        [0.0, -0.0, 1.0, 0.99999994, 1.0000001, 3.9, 4.0, 1e30, 3e38, np.inf, -np.inf, np.nan, 1e-45]]).astype(F)
+    x = np.concatenate([x, rng.integers(0, 2 ** 32, 300000, dtype=np.uint64).astype(np.uint32).view(F)])
+    assert np.array_equal(host.transfer(ctx, x, abi.TRANSFER_PQ, 255), orc.transfer(x, abi.TRANSFER_PQ, 255))
+
+
 def test_srgb_16bit_output_is_exact(ctx, orc):
     """sRGB + 16-bit quantisation: segment table + thresholds (fp_srgb16): the oracle's code value for every input"""
     rng = np.random.default_rng(23)

@@ -22,11 +22,13 @@ ap.add_argument("--out", default="")
 ap.add_argument("--limit", type=int, default=0, help="only the first N chunks (smoke)")
 ap.add_argument("--srgb8", action="store_true", help="instead: sRGB + 8-bit quantisation (the threshold table fp_srgb8) against the oracle, exact equality")
 ap.add_argument("--srgb16", action="store_true", help="instead: sRGB + 16-bit quantisation (fp_srgb16) against the oracle, exact equality")
+ap.add_argument("--pq8", action="store_true", help="instead: PQ + 8-bit quantisation (fp_pq8) against the oracle, exact equality")
 ap.add_argument("--pq16", action="store_true", help="instead: PQ + 16-bit quantisation (fp_pq16: table + threshold correction) against the oracle, exact equality")
 args = ap.parse_args()
-if args.srgb8 or args.pq16 or args.srgb16:
+if args.srgb8 or args.pq16 or args.srgb16 or args.pq8:
     TF, MAXV, NAME = (abi.TRANSFER_SRGB, 255, "sRGB + castToIntWithMax(255), device (threshold table)") if args.srgb8 else \
                      (abi.TRANSFER_SRGB, 65535, "sRGB + castToIntWithMax(65535), device (table + thresholds)") if args.srgb16 else \
+                     (abi.TRANSFER_PQ, 255, "PQ + castToIntWithMax(255), device (thresholds)") if args.pq8 else \
                      (abi.TRANSFER_PQ, 65535, "PQ + castToIntWithMax(65535), device (table + thresholds)")
     ctx = _lib.Context(0)
     n = 1 << args.chunk_log2
