@@ -29,6 +29,9 @@
 
 namespace jxl {
 
+#ifndef JXL_RGB8_PACKED
+#define JXL_RGB8_PACKED 0  // experiment: 12 bytes of a 4-pixel RGB8 run as dword stores (measured slower than 12 byte stores)
+#endif
 #ifndef JXL_EPF3_PH2_WAVES
 #define JXL_EPF3_PH2_WAVES 2
 #endif
@@ -441,6 +444,10 @@ struct OutSink {
                 f4a8* d = reinterpret_cast<f4a8*>((float*)a.out[c] + g);
                 *d = f4a8{o[c][0], o[c][1], o[c][2], o[c][3]};
             }
+            return;
+        }
+        if (JXL_RGB8_PACKED && !PLAIN && n == 4 && (g & 1u) == 0 && a.p.interleaved && a.p.out_elem == 1 && a.p.max_value > 0) {
+            sink_store_rgb8x4(a, g, o);
             return;
         }
 #pragma unroll
