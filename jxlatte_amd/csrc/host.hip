@@ -934,11 +934,12 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
         return fail(nullptr, JXL_ERR_DEVICE, "cannot upload the cosine LUT");
     }
     {
-        static std::vector<float> pq;  // the same for every context of the process
-        if (pq.empty()) {
+        static std::vector<float> pq;  // the same for every context of the process (contexts may be created from several threads)
+        static std::once_flag pq_once;
+        std::call_once(pq_once, [] {
             pq.resize(kPqTableFloats);
             build_pq_table(pq.data());
-        }
+        });
         if (!getenv("JXL_PQ_F64")) {  // experiment knob: keep the double-precision PQ
             if (!c->pq_tab.ensure(sizeof(float) * pq.size()) ||
                 hipMemcpy(c->pq_tab.p, pq.data(), sizeof(float) * pq.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -950,10 +951,11 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     {
         static std::vector<float> st;  // the same for every context of the process
         static bool st_ok = false;
-        if (st.empty()) {
+        static std::once_flag st_once;
+        std::call_once(st_once, [] {
             st.resize(kSrgb8TableFloats);
             st_ok = build_srgb8_table(st.data());
-        }
+        });
         if (st_ok && !getenv("JXL_SRGB8_F64")) {  // experiment knob: keep the double-precision form for 8-bit sRGB output too
             if (!c->srgb8_tab.ensure(sizeof(float) * st.size()) ||
                 hipMemcpy(c->srgb8_tab.p, st.data(), sizeof(float) * st.size(), hipMemcpyHostToDevice) != hipSuccess) {
