@@ -48,12 +48,15 @@ typedef int32_t jxl_status;
 #define JXL_TRANSFER_NONE 0 /* stop after invertXYB: linear float */
 #define JXL_TRANSFER_PQ   1 /* TransferFunction.TF_PQ.fromLinear, TransferFunction.java:83-87 */
 #define JXL_TRANSFER_SRGB 2 /* TransferFunction.TF_SRGB.fromLinearF, :39-44. With 8-bit or 16-bit output (max 255 / 65535) transfer and
-                            * quantisation go through tables of the composite's thresholds: the reference's integer for every float
-                            * input (all 2^32 checked for both); float output evaluates the double pow on the device */
+                            * quantisation go through tables of the composite's thresholds: the ORACLE's integer for every float
+                            * input (all 2^32 checked for both). The thresholds are bisected on the host with glibc's pow(), the
+                            * oracle's form; Java's Math.pow is a HotSpot intrinsic specified to 1 ulp, so a threshold that sits on
+                            * such a disagreement may move one code value against a JVM (unpinned until a JVM runs tests/test_jvm_pin.py).
+                            * Float output evaluates the double pow on the device */
 /* Tolerance of the PQ entries against the reference's (float)Math.pow(double) form. JXL_TRANSFER_PQ evaluates a table of
  * quadratic segments (jxl_fastpow.h): as FLOAT output over ALL 2^32 inputs 99.96 % identical, the rest off by exactly 1 ulp, none
- * worse (profiles/r3_pq_sweep.txt). With 16-bit output (JXL_OUT_U16 / RGB16, max 65535) the quantised sample is the reference's
- * integer for EVERY input (r3: the table value is settled against the composite's 65 535 thresholds, profiles/r3_pq16_sweep.txt);
+ * worse (profiles/r3_pq_sweep.txt). With 16-bit output (JXL_OUT_U16 / RGB16, max 65535) the quantised sample is the oracle's
+ * integer (glibc pow) for EVERY input (r3: the table value is settled against the composite's 65 535 thresholds, profiles/r3_pq16_sweep.txt);
  * an 8-bit PQ sample likewise (binary search in its 255 thresholds, profiles/r3_pq8_sweep.txt). JXL_TRANSFER_PQ_EXACT evaluates the two
  * pow() in double precision on the device (3x the instructions; the pre-round-2 form). Both are accepted by
  * jxl_vardct_params.transfer and jxl_stage_transfer. */

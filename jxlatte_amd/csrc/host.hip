@@ -404,6 +404,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     c->wave_segs.clear();
     static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
+    bool seg_overflow = false;
     auto lay_out = [&](const std::vector<DevBlock>* lists, int channel) {
         std::vector<uint32_t> first_of(JXL_NUM_TRANSFORM_TYPES, 0);
         for (int pass = 0; pass < 2; pass++)
@@ -429,8 +430,11 @@ jxl_status finalize_tables(jxl_ctx* c) {
             for (auto& l : cl)
                 if (l.cls == cls) l.segs.push_back(sg);
         }
-        for (auto& l : cl)
+        for (auto& l : cl) {
+            // the launch argument blocks hold kMaxSeg segments (one per type of a class): checked HERE, where the lists are made
+            if (l.segs.size() > (size_t)std::min(MultiArgs::kMaxSeg, Wg3Args::kMaxSeg)) seg_overflow = true;
             if (!l.segs.empty()) c->type_launches.push_back(std::move(l));
+        }
         jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel, false};
         // One wave per item = 64 consecutive blocks of one type and channel. The block lists are group-major (256 x 256 px
         // groups in raster order), so item k of every type covers about the same few groups. An 8 x 8 block's rows are 32-byte
@@ -494,6 +498,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
             lay_out(sub_lists, ch);
         }
     }
+    if (seg_overflow) return fail(c, JXL_ERR_STATE, "more transform types in one launch class than an argument block holds");
     mark("launch layout");
     c->large_first = (int)c->h_blocks.size();
     for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
@@ -854,7 +859,6 @@ const float* pq16_thresholds_for(jxl_ctx* c, int transfer, int max_value) {
         hipMemcpy(c->pq16_thr.p, thr.data(), sizeof(float) * thr.size(), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
         c->pq16_thr.release();
-    c->srgb16_tab.release();
         return nullptr;
     }
     return c->pq16_thr.as<float>();
@@ -1003,6 +1007,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     c->pq_tab.release();
     c->srgb8_tab.release();
     c->pq16_thr.release();
+    c->srgb16_tab.release();
     for (int i = 0; i < 3; i++) { c->rp[i].release(); c->rp_tmp[i].release(); c->rp_noise[i].release(); }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
@@ -1473,6 +1478,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
             for (const auto& tl : c->type_launches)
                 if (tl.cls >= 2) {
                     wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
+                    if (wn[tl.cls - 2] < 0) return fail(c, JXL_ERR_STATE, "IDCT launch: too many segments");
                     if (c->wg3_item_count[tl.cls - 2] == wn[tl.cls - 2]) wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
                     static const bool wg3_i16 = getenv("JXL_WG3_I16") && atoi(getenv("JXL_WG3_I16")) != 0;
                     if (wg3_i16 && c->coeff16_resident) {  // experiment: the prefetch reads the committed int16 planes
@@ -1485,7 +1491,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                     all.insert(all.end(), tl.segs.begin(), tl.segs.end());
                 }
             if (!all.empty()) {
-                build_wg3_args(f, blocks, all.data(), (int)all.size(), 2, A, wl);
+                if (build_wg3_args(f, blocks, all.data(), (int)all.size(), 2, A, wl) < 0) return fail(c, JXL_ERR_STATE, "IDCT launch: too many segments");
                 for (int q = 0; q < wl.n_seg; q++) any_llf = any_llf || (wl.seg[q].type != 0 && !wl.llf_in_item);
             }
         }
@@ -1821,6 +1827,7 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
                     if (!tl) continue;
                     size_t lds = 0;
                     const int g = build_idct_multi_args(f, c->blocks.as<DevBlock>(), tl->segs.data(), (int)tl->segs.size(), 3, 0, A, a, &lds);
+                    if (g < 0) return fail(c0, JXL_ERR_STATE, "IDCT launch: too many segments");
                     if (g <= 0) continue;
                     bl.grid_x = std::max(bl.grid_x, g);
                     bl.lds_bytes = std::max(bl.lds_bytes, lds);
@@ -1848,6 +1855,7 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
                 if (segs.empty()) continue;
                 Wg3Args a;
                 const int items = build_wg3_args(f, c->blocks.as<DevBlock>(), segs.data(), (int)segs.size(), cls == 10 ? 2 : cls - 11, A, a);
+                if (items < 0) return fail(c0, JXL_ERR_STATE, "IDCT launch: too many segments");
                 if (items <= 0) continue;
                 if (cls != 10 && c->wg3_item_count[cls - 11] == items) a.items = c->wg3_items[cls - 11].as<int>();
                 if (cls == 10) {

@@ -131,7 +131,7 @@ __device__ __forceinline__ float fp_tf_pq_tab(float f, const float4* __restrict_
 // the smallest float that reaches level k (host: build_pq16_thresholds, bisection over bit patterns with the reference's own
 // formula; thr[0] = -inf, thr[65536] = +inf). The table form above gives the level to within +-1 (its float is within 1 ulp,
 // i.e. 0.004 levels, of the reference's), and ONE comparison against the two neighbouring thresholds settles it: the
-// reference's integer for every input (all 2^32 checked: tools/pq_sweep.py --pq16), where the float route alone differs by one
+// oracle's integer (glibc pow) for every input (all 2^32 checked: tools/pq_sweep.py --pq16), where the float route alone differs by one
 // level for 1 input in ~10^4.
 __device__ __forceinline__ int fp_pq16(float f, const float4* __restrict__ tab, const float* __restrict__ thr) {
     if (!(f >= thr[1])) return 0;      // below the first threshold, negative, zero, NaN

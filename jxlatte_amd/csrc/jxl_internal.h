@@ -223,6 +223,9 @@ void launch_restore_stream(const FusedArgs& a, hipStream_t s);
 bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                              const int32_t* sharpness, const RestoreParams& p, FusedArgs& a);
 int restore_fused_variant(const FusedArgs& a);  // which kernel instantiation the arguments select
+// the non-float sinks of the fused kernel (k_restore_fused_gen.hip, k_restore_fused_q.hip): one frame (`single`) or a batch
+void launch_restore_fused_gen(const FusedArgs* single, const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s);
+void launch_restore_fused_q(int sink_kind, const FusedArgs* single, const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s);
 void launch_restore_fused_batch(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s);
 // returns false if the configuration is not covered by the fused kernel (caller falls back to stage kernels)
 bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,

@@ -1124,8 +1124,9 @@ int build_idct_multi_args(const DevFrame& f, const DevBlock* blocks, const IdctS
     a.n_seg = 0;
     int b0 = 0;
     size_t lds_bytes = 0;
-    for (int i = 0; i < n_seg && a.n_seg < MultiArgs::kMaxSeg; i++) {
+    for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0) continue;
+        if (a.n_seg >= MultiArgs::kMaxSeg) return -1;  // never drop blocks silently (finalize_tables checks the lists it builds)
         const int k = a.n_seg++;
         const int nb = medium_blocks_per_wg(segs[i].type);
         const int tt_h = JXL_TT[segs[i].type].ph, tt_w = JXL_TT[segs[i].type].pw;

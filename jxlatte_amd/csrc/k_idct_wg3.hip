@@ -845,7 +845,8 @@ static int wg3_img_floats(int type) {
 }
 
 // Fills the argument block for the frame's types of one register class (which = 0: up to 32 points, 1: the 64-point family;
-// 2: both, for the LLF launch), in the given launch order. Returns the number of items (0: nothing to launch).
+// 2: both, for the LLF launch), in the given launch order. Returns the number of items (0: nothing to launch; -1: more
+// segments than the argument block holds).
 int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],
                    Wg3Args& a) {
     a.f = f;
@@ -861,10 +862,9 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
     for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
-        if (a.n_seg >= Wg3Args::kMaxSeg) {  // a type twice in the list, or a new type without a larger kMaxSeg: never drop blocks silently
-            fprintf(stderr, "jxlatte_amd: build_wg3_args: more than %d segments\n", Wg3Args::kMaxSeg);
-            abort();
-        }
+        // a type twice in the list, or a new type without a larger kMaxSeg: never drop blocks silently, never kill the host
+        // process (finalize_tables checks the lists it builds and reports JXL_ERR_STATE)
+        if (a.n_seg >= Wg3Args::kMaxSeg) return -1;
         Wg3Seg& sg = a.seg[a.n_seg++];
         const int nb = wg3_blocks_per_item(segs[i].type);
         sg.type = segs[i].type;

@@ -1,726 +1,12 @@
-// Fused restoration + colour tile kernel for gfx950:
-//   Gaborish -> EPF iteration(s) -> XYB->linear -> (transfer + quantise) in ONE launch, one read and
-//   one write of the frame planes; all intermediates live in LDS.
+// Fused restoration + colour tile kernel for gfx950 (kernel template: restore_fused_body.h): the float-plane instantiations -- the
+// hot variants of the 4K / batch workload -- and the entry points. The other output sinks are instantiated in
+// k_restore_fused_gen.hip (run-time-generic) and k_restore_fused_q.hip (quantised PNG / u16 formats fixed at compile time).
 //
-// Replaces the same reference functions as k_restore.hip (Frame.java:505-679,
-// OpsinInverseMatrix.java:105-142, JXLImage.java:244-258, ImageBuffer.java:129-147) and is checked
-// bit-for-bit against them through the oracle AND against the stage kernels.
-//
-// Geometry (template <GAB, ITERS, PLAIN, PH>): the most expensive stage -- the first EPF iteration that runs -- is computed on a
-// 64x32 window = 512 threads x (4 wide x 1 tall) register patches (PH = 2: 256 threads x 4x2 patches, measured slower). Later
-// iterations shrink the window by their radius (iteration 1: 2 px of input halo, iteration 2: 1, iteration 0: 3), Gaborish
-// adds 1. E.g. the default (Gab + iterations 1,2): input tile 70x38 -> Gab 68x36 -> EPF1 64x32 -> EPF2 62x30 output tile.
-// ONE LDS image of 3 planes (~34 KB) that every stage updates IN PLACE: a thread computes the patch it owns into registers, the
-// workgroup meets at a barrier (all reads of the old values done), then the patches are written back over the input
-// (4 workgroups per CU = 8 waves per SIMD at 63 VGPRs).
-//
-// Exactness: per pixel the EPF distance is the reference's strictly sequential sum
-//   dist = (((0 + |a-b|*s0) + ...)            channel-major, cross order (0,0),(0,-1),(0,1),(-1,0),(1,0)
-// Every |P(u) - P(v)| * scale term is written with canonically ordered operands (|x-y| == |y-x| exactly)
-// so the compiler's value numbering shares the terms between the pixels and taps of a patch instead of
-// recomputing them. The centre tap has distance exactly 0 and weight exactly 1 for finite samples (the
-// IDCT output is finite), so it is folded: sumWeights starts at 1, sumChannels at the centre sample.
-// Frame edges: Gab reads clamped coordinates, EPF reads mirrored ones (MathHelper.mirrorCoordinate);
-// edge tiles re-create that by copying mirrored positions inside LDS after each stage.
-#include "jxl_internal.h"
-#include <algorithm>
-#include "restore_sink.h"
-#include <cstdlib>
+// Replaces Frame.java:505-679, OpsinInverseMatrix.java:105-142, JXLImage.java:244-258, ImageBuffer.java:129-147,
+// PNGWriter.java:65,105-111 (see the header).
+#include "restore_fused_body.h"
 
 namespace jxl {
-
-#ifndef JXL_RGB8_PACKED
-#define JXL_RGB8_PACKED 0  // experiment: 12 bytes of a 4-pixel RGB8 run as dword stores (measured slower than 12 byte stores)
-#endif
-#ifndef JXL_EPF3_PH2_WAVES
-#define JXL_EPF3_PH2_WAVES 2
-#endif
-
-namespace {
-
-__device__ __forceinline__ int mirror_c(int c, int size) {
-    while (c < 0 || c >= size) {
-        const int tc = ~c;
-        c = tc >= 0 ? tc : (size << 1) + tc;
-    }
-    return c;
-}
-
-template <bool GAB, int ITERS>
-struct Geo {
-    static constexpr int RG = GAB ? 1 : 0;
-    static constexpr int R0 = ITERS == 3 ? 3 : 0;
-    static constexpr int R1 = ITERS >= 1 ? 2 : 0;
-    static constexpr int R2 = ITERS >= 2 ? 1 : 0;
-    static constexpr int SHR = ITERS == 3 ? (R1 + R2) : ITERS == 2 ? R2 : 0;  // window -> output tile
-    static constexpr int OW = 64 - 2 * SHR, OH = 32 - 2 * SHR;               // output tile
-    static constexpr int RE = R0 + R1 + R2;
-    static constexpr int RT = RE + RG;                                        // input halo
-    static constexpr int IW = OW + 2 * RT, IH = OH + 2 * RT;                  // input tile
-    static constexpr int SW = IW + 3;                                         // LDS row stride (patch over-read <= 3)
-    static constexpr int SH = IH + 1;
-    static constexpr int PLANE = SW * SH;
-    static constexpr size_t LDS_BYTES = sizeof(float) * (3 * PLANE + 16 * 16);
-};
-
-// canonical |P[u] - P[v]| * s: operands ordered by index so equal terms are literally the same expression
-template <int PS>
-__device__ __forceinline__ float adiff(const float* p, int u, int v, float s) {
-    return u < v ? fabsf(p[u] - p[v]) * s : fabsf(p[v] - p[u]) * s;
-}
-
-// One EPF iteration (Frame.java:583-635) on a 4x2 patch whose top-left sample is (ry, rx) in region
-// coordinates of src (3 planes, stride SW). Results for the 8 pixels go to res[c][py*4+px].
-// ITER: 0 = 13 taps with cross distances, 1 = 5 taps with cross distances, 2 = 5 taps single-pixel.
-template <int ITER, int SW, int PLANE, int PH, bool CHAINS = true>
-__device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry, int rx, const float* s_inv /*[NP]*/,
-                                          const float* bmul /*[NP]*/, const EpfParams& ep, float res[3][4 * PH]) {
-    constexpr int NP = 4 * PH;  // pixels per patch
-    constexpr int R = ITER == 0 ? 3 : ITER == 1 ? 2 : 1;  // neighbourhood radius
-    constexpr int NW = 4 + 2 * R, NH = PH + 2 * R;
-    constexpr int NT = ITER == 0 ? 12 : 4;  // non-centre taps
-    // (dy, dx) in the reference's order, centre tap folded (Frame.java:44-55)
-    constexpr int TY[12] = {0, 0, -1, 1, -1, 1, 1, -1, 0, 0, 2, -2};
-    constexpr int TX[12] = {-1, 1, 0, 0, 1, 1, -1, -1, -2, 2, 0, 0};
-    constexpr int QY[5] = {0, 0, 0, -1, 1};
-    constexpr int QX[5] = {0, -1, 1, 0, 0};
-
-    float dist[NP][NT];
-#pragma unroll
-    for (int i = 0; i < NP; i++)
-#pragma unroll
-        for (int t = 0; t < NT; t++) dist[i][t] = 0.0f;
-
-    if (ITER != 0 && CHAINS) {
-        // The distance of pixel p to its east neighbour IS the distance of p+1 to its west neighbour: the same
-        // terms |P(p+k) - P(p+1+k)| * s in the same channel-major, cross-minor order (likewise south/north). So a
-        // patch needs one chain per horizontally / vertically adjacent pixel PAIR, not one per (pixel, tap):
-        //   hc[py][j] = distance between (py, j-1) and (py, j), j = 0..4;  vc[i][px] = between (i-1, px) and (i, px), i = 0..PH
-        float hc[PH][5], vc[PH + 1][4];
-#pragma unroll
-        for (int py = 0; py < PH; py++)
-#pragma unroll
-            for (int j = 0; j < 5; j++) hc[py][j] = 0.0f;
-#pragma unroll
-        for (int i = 0; i <= PH; i++)
-#pragma unroll
-            for (int px = 0; px < 4; px++) vc[i][px] = 0.0f;
-#pragma unroll 1
-        for (int c = 0; c < 3; c++) {
-            float nb[NH * NW];
-            const float* pc = src + c * PLANE + (ry - R) * SW + (rx - R);
-#pragma unroll
-            for (int y = 0; y < NH; y++)
-#pragma unroll
-                for (int x = 0; x < NW; x++) nb[y * NW + x] = pc[y * SW + x];
-            const float sc = ep.channel_scale[c];
-#pragma unroll
-            for (int py = 0; py < PH; py++)
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const int cy = py + R, cx = j - 1 + R;
-                    if (ITER == 2) hc[py][j] = hc[py][j] + adiff<NW>(nb, cy * NW + cx, cy * NW + cx + 1, sc);
-                    else
-#pragma unroll
-                        for (int q = 0; q < 5; q++) {
-                            const int u = (cy + QY[q]) * NW + cx + QX[q];
-                            hc[py][j] = hc[py][j] + adiff<NW>(nb, u, u + 1, sc);
-                        }
-                }
-#pragma unroll
-            for (int i = 0; i <= PH; i++)
-#pragma unroll
-                for (int px = 0; px < 4; px++) {
-                    const int cy = i - 1 + R, cx = px + R;
-                    if (ITER == 2) vc[i][px] = vc[i][px] + adiff<NW>(nb, cy * NW + cx, (cy + 1) * NW + cx, sc);
-                    else
-#pragma unroll
-                        for (int q = 0; q < 5; q++) {
-                            const int u = (cy + QY[q]) * NW + cx + QX[q];
-                            vc[i][px] = vc[i][px] + adiff<NW>(nb, u, u + NW, sc);
-                        }
-                }
-        }
-#pragma unroll
-        for (int py = 0; py < PH; py++)
-#pragma unroll
-            for (int px = 0; px < 4; px++) {
-                dist[py * 4 + px][0] = hc[py][px];      // tap (0,-1)
-                dist[py * 4 + px][1] = hc[py][px + 1];  // tap (0,+1)
-                dist[py * 4 + px][2] = vc[py][px];      // tap (-1,0)
-                dist[py * 4 + px][3] = vc[py + 1][px];  // tap (+1,0)
-            }
-    } else {
-    // 13-tap iteration: the four taps on the patch's own row -- (0,-1), (0,1), (0,-2), (0,2) -- are pair distances that two pixels of
-    // the 4x1 patch share (dist(p, p + t) and dist(p + t, p) are the same terms in the same order): 5 + 6 chains instead of 16.
-    // The other eight taps pair a pixel with one of another row, i.e. of another thread's patch.
-    constexpr bool HROW = ITER == 0 && CHAINS && PH == 1;
-    float h1[5], h2[6];
-#pragma unroll
-    for (int j = 0; j < 5; j++) h1[j] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 6; j++) h2[j] = 0.0f;
-    // channels one after the other (not interleaved by the scheduler): keeps the live set under 128 VGPRs
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-        // neighbourhood of this channel in registers; only the diamond of radius R around the patch is
-        // ever referenced, the compiler drops the unused corner loads
-        float nb[NH * NW];
-        const float* pc = src + c * PLANE + (ry - R) * SW + (rx - R);
-#pragma unroll
-        for (int y = 0; y < NH; y++)
-#pragma unroll
-            for (int x = 0; x < NW; x++) nb[y * NW + x] = pc[y * SW + x];
-        const float sc = ep.channel_scale[c];
-#pragma unroll
-        for (int py = 0; py < PH; py++)
-#pragma unroll
-            for (int px = 0; px < 4; px++) {
-                const int cy = py + R, cx = px + R;  // centre inside nb
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    if (HROW && TY[t] == 0) continue;  // through h1 / h2 below
-                    if (ITER == 2) {  // epfDistance2 (:657-669): single pixel
-                        dist[py * 4 + px][t] =
-                            dist[py * 4 + px][t] + adiff<NW>(nb, cy * NW + cx, (cy + TY[t]) * NW + cx + TX[t], sc);
-                    } else {  // epfDistance1 (:638-655): 5-point cross
-#pragma unroll
-                        for (int q = 0; q < 5; q++) {
-                            const int u = (cy + QY[q]) * NW + cx + QX[q];
-                            const int v = (cy + TY[t] + QY[q]) * NW + cx + TX[t] + QX[q];
-                            dist[py * 4 + px][t] = dist[py * 4 + px][t] + adiff<NW>(nb, u, v, sc);
-                        }
-                    }
-                }
-            }
-        if (HROW) {
-            constexpr int cy = R;
-#pragma unroll
-            for (int j = 0; j < 5; j++)
-#pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    const int u = (cy + QY[q]) * NW + (j - 1 + R) + QX[q];
-                    h1[j] = h1[j] + adiff<NW>(nb, u, u + 1, sc);
-                }
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-#pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    const int u = (cy + QY[q]) * NW + (j - 2 + R) + QX[q];
-                    h2[j] = h2[j] + adiff<NW>(nb, u, u + 2, sc);
-                }
-        }
-    }
-    if (HROW) {
-#pragma unroll
-        for (int px = 0; px < 4; px++)
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                if (TY[t] != 0) continue;
-                dist[px][t] = TX[t] == -1 ? h1[px] : TX[t] == 1 ? h1[px + 1] : TX[t] == -2 ? h2[px] : h2[px + 2];
-            }
-    }
-    }
-    // weights (epfWeight, :671-679), in place of the distances
-    float sumW[NP];
-    bool skip[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const float s = s_inv[i];
-        skip[i] = (s != s) || (s > (1.0f / 0.3f));  // :608-612
-        float sw = 0.0f + 1.0f;                     // centre tap: dist 0 -> weight 1 (finite samples)
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const float d = dist[i][t] * bmul[i];
-            const float v = 1.0f - d * ep.sigma_scale * s;
-            const float w = v < 0.0f ? 0.0f : v;
-            dist[i][t] = w;
-            sw = sw + w;
-        }
-        sumW[i] = sw;
-    }
-    // weighted sums per channel (:615-626): tap radius RT2 only
-    constexpr int RT2 = ITER == 0 ? 2 : 1;
-    constexpr int MW = 4 + 2 * RT2, MH = PH + 2 * RT2;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float nb[MH * MW];
-        const float* pc = src + c * PLANE + (ry - RT2) * SW + (rx - RT2);
-#pragma unroll
-        for (int y = 0; y < MH; y++)
-#pragma unroll
-            for (int x = 0; x < MW; x++) nb[y * MW + x] = pc[y * SW + x];
-#pragma unroll
-        for (int py = 0; py < PH; py++)
-#pragma unroll
-            for (int px = 0; px < 4; px++) {
-                const int i = py * 4 + px;
-                const int cy = py + RT2, cx = px + RT2;
-                float sc = 0.0f + nb[cy * MW + cx] * 1.0f;
-#pragma unroll
-                for (int t = 0; t < NT; t++) sc = sc + nb[(cy + TY[t]) * MW + cx + TX[t]] * dist[i][t];
-#ifdef JXL_EPF_DIV_BRANCH
-                res[c][i] = skip[i] ? nb[cy * MW + cx] : sc / sumW[i];
-#else
-                // the quotient is formed unconditionally (the empty asm keeps the optimiser from sinking the division into
-                // a branch on `skip`): twelve exec-masked blocks per stage become straight-line code, and the schedulers
-                // interleave the twelve dependent rcp / fma chains
-                float qv = sc / sumW[i];
-                asm volatile("" : "+v"(qv));
-                res[c][i] = skip[i] ? nb[cy * MW + cx] : qv;
-#endif
-            }
-    }
-}
-
-struct TileCtx {
-    int ix0, iy0;  // frame coordinates of region (0,0)
-    int W, H;
-    bool edge;
-};
-
-// s_inv / border factor of the 4 x PH pixels of a patch
-template <int PH>
-__device__ __forceinline__ void patch_sigma(int ry, int rx, const TileCtx& tc, const float* __restrict__ sig, int scy0, int scx0,
-                                            const EpfParams& ep, float s_inv[4 * PH], float bmul[4 * PH]) {
-    const int gx0 = tc.ix0 + rx;
-    // a 4-pixel run touches at most two cells: look up the first and the last, pick per pixel. Out-of-frame
-    // positions (only on edge tiles) get some in-range cell; they are recomputed by the mirror fix-up.
-    const int cxa = (min(max(gx0, 0), tc.W - 1) >> 3) - scx0, cxb = (min(max(gx0 + 3, 0), tc.W - 1) >> 3) - scx0;
-#pragma unroll
-    for (int py = 0; py < PH; py++) {
-        const int gy = tc.iy0 + ry + py;
-        const bool rowb = ((gy + 1) & 7) < 2;  // gy & 7 is 7 or 0
-        const int crow = ((min(max(gy, 0), tc.H - 1) >> 3) - scy0) * 16;
-        const float sa = sig[crow + cxa], sb = sig[crow + cxb];
-#pragma unroll
-        for (int px = 0; px < 4; px++) {
-            const int gx = gx0 + px;
-            // epfWeight's border factor (:672-675): border_sad_mul on 8x8-border rows/columns, else 1 (d * 1 == d)
-            bmul[py * 4 + px] = (rowb || ((gx + 1) & 7) < 2) ? ep.border_sad_mul : 1.0f;
-            s_inv[py * 4 + px] = (gx >> 3) == (gx0 >> 3) ? sa : sb;
-        }
-    }
-}
-
-// run one EPF iteration over the output region [m, IH-m) x [m, IW-m) of the tile.
-// LAST: results go to the sink (colour + global store). Otherwise IN PLACE: every thread computes the one patch it owns
-// into registers, the workgroup meets at a barrier (all reads of the old values done), then the patches are written
-// back over the input. One LDS buffer instead of two doubles the workgroups a CU can hold.
-template <int ITER, typename G, bool LAST, int PH, typename Sink>
-__device__ __forceinline__ void epf_stage(float* buf, int m, const TileCtx& tc, const float* __restrict__ sig, int scy0, int scx0,
-                                          const EpfParams& ep, Sink sink) {
-    constexpr int SW = G::SW, PLANE = G::PLANE;
-    const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
-    constexpr int NTHR = 512 / PH;
-    const int pcols = (rw + 3) >> 2, prows = (rh + PH - 1) / PH;
-    // thread -> patch. LDS banks are (address / 4) mod 32 for ds_read_b32 / ds_read2 / ds_write, and lanes conflict within a
-    // 32-lane half. A patch is 4 floats wide, so 16 patches of one row put their first words on only 8 banks: the row-major
-    // assignment (lane -> 16 patches x 2 rows) made every tap read and every write-back a 2-way conflict (44 % of all LDS
-    // cycles, profiles/r1). With 8 patches x 4 rows per half the rows add 0, SW, 2 SW, 3 SW: SW is odd, so they land in the
-    // four residue classes mod 4 and the 32 lanes cover the 32 banks exactly once. Any constant tap offset keeps that.
-    const int cblocks = (pcols + 7) >> 3, n_groups = cblocks * ((prows + 3) >> 2);
-    const int q = threadIdx.x & 31;
-    auto patch_of = [&](int g, int& prow, int& pcol) {
-        pcol = (g % cblocks) * 8 + (q & 7);
-        prow = (g / cblocks) * 4 + (q >> 3);
-        return prow < prows && pcol < pcols;
-    };
-    if (LAST) {
-        for (int g = threadIdx.x >> 5; g < n_groups; g += NTHR / 32) {
-            int prow, pcol;
-            if (!patch_of(g, prow, pcol)) continue;
-            const int ry = m + prow * PH, rx = m + pcol * 4;
-            float s_inv[4 * PH], bmul[4 * PH];
-            patch_sigma<PH>(ry, rx, tc, sig, scy0, scx0, ep, s_inv, bmul);
-            float res[3][4 * PH];
-            epf_patch<ITER, SW, PLANE, PH>(buf, ry, rx, s_inv, bmul, ep, res);
-#pragma unroll
-            for (int py = 0; py < PH; py++) {
-                const int y = ry + py;
-                if (y < G::IH - m) sink.row4(y, rx, &res[0][py * 4], &res[1][py * 4], &res[2][py * 4], min(4, G::IW - m - rx));
-            }
-        }
-    } else {
-        // the largest region any stage sees is the 64x32 window: one patch per thread
-        static_assert((64 / 4) * ((32 + PH - 1) / PH) <= NTHR, "one patch per thread");
-        int prow, pcol;
-        const bool act = patch_of(threadIdx.x >> 5, prow, pcol);  // 16 groups of 8 x 4 patches cover the 16 x 32 window
-        const int ry = m + prow * PH, rx = m + pcol * 4;
-        float res[3][4 * PH];
-        if (act) {
-            float s_inv[4 * PH], bmul[4 * PH];
-            patch_sigma<PH>(ry, rx, tc, sig, scy0, scx0, ep, s_inv, bmul);
-            epf_patch<ITER, SW, PLANE, PH>(buf, ry, rx, s_inv, bmul, ep, res);
-        }
-        __syncthreads();
-        if (act) {
-#pragma unroll
-            for (int py = 0; py < PH; py++) {
-                const int y = ry + py;
-#pragma unroll
-                for (int px = 0; px < 4; px++) {
-                    const int x = rx + px;
-                    if (y < G::IH - m && x < G::IW - m) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++) buf[c * PLANE + y * SW + x] = res[c][py * 4 + px];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// after a non-final stage on an edge tile: positions of the region outside the frame take the value of
-// their mirrored in-frame position (what a mirrored read of the full-frame plane would return)
-template <typename G, int NTHR>
-__device__ __forceinline__ void mirror_fixup(float* __restrict__ buf, int m, int rem, const TileCtx& tc) {
-    const int rw = G::IW - 2 * m, rh = G::IH - 2 * m;
-    __syncthreads();
-    for (int i = threadIdx.x; i < rw * rh; i += NTHR) {
-        const int y = m + i / rw, x = m + i % rw;
-        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
-        const bool outside = gy < 0 || gy >= tc.H || gx < 0 || gx >= tc.W;
-        // only positions within the radius the remaining stages can reach from an in-frame pixel matter
-        const bool near = gy >= -rem && gy < tc.H + rem && gx >= -rem && gx < tc.W + rem;
-        if (outside && near) {
-            const int my = mirror_c(gy, tc.H) - tc.iy0, mx = mirror_c(gx, tc.W) - tc.ix0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) buf[c * G::PLANE + y * G::SW + x] = buf[c * G::PLANE + my * G::SW + mx];
-        }
-    }
-}
-
-
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-struct __attribute__((packed, aligned(4))) f2a4 {
-    float x, y;
-};
-struct __attribute__((packed, aligned(8))) f4a8 {
-    float x, y, z, w;
-};
-
-// OpsinInverseMatrix.invertXYB + JXLImage.transferInPlace + ImageBuffer.castToInt0 + the global store
-template <bool PLAIN>
-struct OutSink {
-    const FusedArgs& a;
-    const TileCtx& tc;
-    __device__ __forceinline__ void colour(float& v0, float& v1, float& v2) const {
-        if (a.p.xyb) sink_colour(a.p.xybp, v0, v1, v2);
-    }
-    __device__ __forceinline__ void store1(uint32_t g, float v0, float v1, float v2) const { sink_store<PLAIN>(a, g, v0, v1, v2); }
-    // one pixel at region position (y, x)
-    __device__ __forceinline__ void operator()(int y, int x, float v0, float v1, float v2) const {
-        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
-        if (gy >= tc.H || gx >= tc.W) return;
-        colour(v0, v1, v2);
-        store1((uint32_t)(gy * tc.W + gx), v0, v1, v2);
-    }
-    // up to 4 consecutive pixels of a row (a patch row); float planes leave as 8-byte stores when aligned
-    __device__ __forceinline__ void row4(int y, int x, const float* r0, const float* r1, const float* r2, int nvalid) const {
-        const int gy = tc.iy0 + y, gx = tc.ix0 + x;
-        if (gy >= tc.H) return;
-        const int n = min(nvalid, tc.W - gx);
-        if (n <= 0) return;
-        float o[3][4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            o[0][i] = r0[i];
-            o[1][i] = r1[i];
-            o[2][i] = r2[i];
-            colour(o[0][i], o[1][i], o[2][i]);
-        }
-        const uint32_t g = (uint32_t)(gy * tc.W + gx);
-#ifdef JXL_ABL_NOSTORE  // timing ablation only: the values are computed, (practically) never stored
-        if (o[0][0] != 1.2345e-30f || o[1][1] != 1.2345e-30f || o[2][2] != 1.2345e-30f || o[0][3] != 1.5e-30f || o[1][3] != 1.5e-30f || o[2][0] != 1.5e-30f ||
-            o[0][1] != 1.5e-30f || o[0][2] != 1.5e-30f || o[1][0] != 1.5e-30f || o[1][2] != 1.5e-30f || o[2][1] != 1.5e-30f || o[2][3] != 1.5e-30f) return;
-#endif
-        if (PLAIN && n == 4 && (g & 1u) == 0) {
-            // one 16-byte store per lane and channel: a wave instruction then covers whole rows of 256 contiguous
-            // bytes instead of every other 8 bytes (tile origins are multiples of 62 px: 8-byte aligned, so the
-            // store is declared 8-byte aligned; gfx950 global stores do not need 16-byte alignment)
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                f4a8* d = reinterpret_cast<f4a8*>((float*)a.out[c] + g);
-                *d = f4a8{o[c][0], o[c][1], o[c][2], o[c][3]};
-            }
-            return;
-        }
-        if (JXL_RGB8_PACKED && !PLAIN && n == 4 && (g & 1u) == 0 && a.p.interleaved && a.p.out_elem == 1 && a.p.max_value > 0) {
-            sink_store_rgb8x4(a, g, o);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (i < n) store1(g + i, o[0][i], o[1][i], o[2][i]);
-    }
-};
-
-// PLAIN = true: float planes out, no transfer function (keeps the double-precision pow() code of the
-// PQ/sRGB transfer out of the hot variant)
-template <bool GAB, int ITERS, bool PLAIN, int PH>
-__device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
-    using G = Geo<GAB, ITERS>;
-    constexpr int NTHR = 512 / PH;
-    extern __shared__ float lds[];
-    float* A = lds;                   // the tile: 3 planes, every stage works in place
-    float* sig = lds + 3 * G::PLANE;  // [16][16] inverse sigma of the cells under the tile
-    const int W = a.W, H = a.H;
-    TileCtx tc;
-    tc.W = W;
-    tc.H = H;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b % 8 share an L2), so give every
-    // XCD one contiguous run of tiles in raster order: neighbouring tiles (shared halo reads, shared 128-byte
-    // lines of the 62-wide output rows) then meet in the same L2. Speed only, never correctness.
-    const int tiles_x = (W + G::OW - 1) / G::OW, tiles_y = (H + G::OH - 1) / G::OH;
-    int ox, oy;
-    if (a.ring_only) {
-        // only the tiles that hold pixels of the frame-edge ring (the interior belongs to k_restore_stream): every tile of the
-        // top / bottom border rows, then the left / right border tiles of the rows between (see ring_tile_count)
-        const int nTB = a.ring_ty > 0 ? 1 + tiles_y - a.ring_ty : tiles_y;
-        const int nLR = a.ring_tx > 0 ? 1 + tiles_x - a.ring_tx : tiles_x;
-        const int idx = (int)blockIdx.x;
-        int tx, ty;
-        if (idx < tiles_x * nTB) {
-            const int j = idx / tiles_x;
-            tx = idx - j * tiles_x;
-            ty = a.ring_ty > 0 ? (j == 0 ? 0 : a.ring_ty + j - 1) : j;
-        } else {
-            const int i2 = idx - tiles_x * nTB;
-            const int row = i2 / nLR, k = i2 - row * nLR;
-            ty = row + 1;
-            tx = a.ring_tx > 0 ? (k == 0 ? 0 : a.ring_tx + k - 1) : k;
-            if (ty >= a.ring_ty) return;  // uniform per workgroup, before any barrier
-        }
-        ox = tx * G::OW;
-        oy = ty * G::OH;
-    } else {
-        const int n_tiles = tiles_x * tiles_y;
-        const int per_xcd = (n_tiles + 7) >> 3;
-        const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
-        if (tile >= n_tiles) return;  // uniform per workgroup, before any barrier
-        ox = (tile % tiles_x) * G::OW;
-        oy = (tile / tiles_x) * G::OH;
-    }
-    tc.ix0 = ox - G::RT;
-    tc.iy0 = oy - G::RT;
-    tc.edge = tc.ix0 < 0 || tc.iy0 < 0 || tc.ix0 + G::IW > W || tc.iy0 + G::IH > H;
-
-    // inverse sigma per cell (Frame.java:552-571)
-    const int scy0 = max(tc.iy0, 0) >> 3, scx0 = max(tc.ix0, 0) >> 3;
-    if (ITERS > 0) {
-        const int cy = scy0 + ((threadIdx.x & 255) >> 4), cx = scx0 + (threadIdx.x & 15);
-        float v = 0.0f;
-        if (cy < ((H + 7) >> 3) && cx < a.bw) {
-            const int sharp = a.sharpness[cy * a.bw + cx] & 7;
-            const float sigma = a.p.global_scale_f * a.p.sharp_lut[sharp] / (float)a.hf_mul[cy * a.bw + cx];
-            v = 1.0f / sigma;
-        }
-        sig[threadIdx.x & 255] = v;
-    }
-    // load the input tile: clamped coordinates feed Gab, mirrored ones feed EPF directly. Flat row-major
-    // walk with incrementally updated (y, x) and 32-bit plane offsets (scalar base + 32-bit lane offset).
-    if (!tc.edge) {
-        // interior tile: no coordinate fix-ups; two samples per lane and load (the tile origin is only 4-byte aligned)
-        static_assert(G::IW % 2 == 0, "pairs");
-        constexpr int PAIRS = G::IW / 2, TOTAL = PAIRS * G::IH;
-        const uint32_t base = (uint32_t)(tc.iy0 * W + tc.ix0);
-#pragma unroll
-        for (int k = 0; k < (TOTAL + NTHR - 1) / NTHR; k++) {
-            const int idx = (int)threadIdx.x + k * NTHR;
-            if (idx < TOTAL) {
-                const int y = idx / PAIRS, x = (idx - y * PAIRS) * 2;
-                const uint32_t g = base + (uint32_t)(y * W + x);
-#ifdef JXL_ABL_NOLOAD  // timing ablation only (wrong results): no global loads
-                const float fg = (float)(g & 1023u) * 0.001f;
-                const f2a4 v0{fg, fg + 0.5f}, v1{fg * 0.5f, fg}, v2{fg + 0.25f, fg * 2.0f};
-#else
-                const f2a4 v0 = *reinterpret_cast<const f2a4*>(a.in[0] + g);
-                const f2a4 v1 = *reinterpret_cast<const f2a4*>(a.in[1] + g);
-                const f2a4 v2 = *reinterpret_cast<const f2a4*>(a.in[2] + g);
-#endif
-                float* d = A + y * G::SW + x;
-                d[0] = v0.x;
-                d[1] = v0.y;
-                d[G::PLANE] = v1.x;
-                d[G::PLANE + 1] = v1.y;
-                d[2 * G::PLANE] = v2.x;
-                d[2 * G::PLANE + 1] = v2.y;
-            }
-        }
-    } else {
-        constexpr int STEP_Y = NTHR / G::IW, STEP_X = NTHR % G::IW;
-        int y = threadIdx.x / G::IW, x = threadIdx.x % G::IW;
-        const float* __restrict__ in0 = a.in[0];
-        const float* __restrict__ in1 = a.in[1];
-        const float* __restrict__ in2 = a.in[2];
-        while (y < G::IH) {
-            int gy = tc.iy0 + y, gx = tc.ix0 + x;
-            if (GAB) {
-                gy = min(max(gy, 0), H - 1);
-                gx = min(max(gx, 0), W - 1);
-            } else {
-                gy = mirror_c(gy, H);
-                gx = mirror_c(gx, W);
-            }
-            const uint32_t g = (uint32_t)(gy * W + gx);
-            const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
-            float* d = A + y * G::SW + x;
-            d[0] = v0;
-            d[G::PLANE] = v1;
-            d[2 * G::PLANE] = v2;
-            x += STEP_X;
-            y += STEP_Y;
-            if (x >= G::IW) {
-                x -= G::IW;
-                y++;
-            }
-        }
-    }
-    __syncthreads();
-    float* cur = A;
-    int m = 0;
-    if (GAB) {  // Frame.performGabConvolution (:505-542). Lane = column (consecutive lanes = consecutive x: conflict-free
-                // LDS rows), walking down a segment of rows with the 3x3 neighbourhood sliding through registers: three
-                // new samples and 10 flops per output. (W + E) of a row is the first partial sum of both its own `adj`
-                // and of the `diag` of the row below -- same operands, same order -- so it is formed once.
-        m = 1;
-        constexpr int rw = G::IW - 2, rh = G::IH - 2;
-        constexpr int NCOLSEG = NTHR / rw;                         // row segments worked on at once
-        constexpr int SEG = (rh + NCOLSEG - 1) / NCOLSEG;          // rows per segment
-        constexpr int NSEG = (rh + SEG - 1) / SEG;
-        static_assert(NSEG * rw <= NTHR, "one pass");
-        const int seg = threadIdx.x / rw, x = threadIdx.x - seg * rw;
-        const int y0 = seg * SEG;
-        float go[3][SEG];
-        if (seg < NSEG) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float* p = cur + c * G::PLANE + y0 * G::SW + x;
-                float a0 = p[0], a1 = p[1], a2 = p[2];
-                float b0 = p[G::SW], b1 = p[G::SW + 1], b2 = p[G::SW + 2];
-                float hs_a = a0 + a2;
-                const float wb = a.p.gab_base[c], wa = a.p.gab_adj[c], wd = a.p.gab_diag[c];
-#pragma unroll
-                for (int k = 0; k < SEG; k++) {
-                    if (y0 + k < rh) {
-                        const float c0 = p[(k + 2) * G::SW], c1 = p[(k + 2) * G::SW + 1], c2 = p[(k + 2) * G::SW + 2];
-                        const float hs_b = b0 + b2;
-                        const float adj = hs_b + a1 + c1;    // p[-1] + p[1] + p[-SW] + p[SW]
-                        const float diag = hs_a + c0 + c2;   // p[-SW-1] + p[-SW+1] + p[SW-1] + p[SW+1]
-                        go[c][k] = wb * b1 + wa * adj + wd * diag;
-                        a1 = b1;
-                        hs_a = hs_b;
-                        b0 = c0; b1 = c1; b2 = c2;
-                    }
-                }
-            }
-        }
-        __syncthreads();  // every read of the un-filtered tile is done: write the results over it
-        if (seg < NSEG) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float* o = cur + c * G::PLANE + (y0 + 1) * G::SW + x + 1;
-#pragma unroll
-                for (int k = 0; k < SEG; k++)
-                    if (y0 + k < rh) o[k * G::SW] = go[c][k];
-            }
-        }
-        if (tc.edge && ITERS > 0) mirror_fixup<G, NTHR>(cur, m, G::RE, tc);
-        __syncthreads();
-    }
-
-    // final sink: XYB + transfer/quantise + global store
-    const OutSink<PLAIN> sink{a, tc};
-
-    if (ITERS == 0) {
-        const int mm = m;
-        for (int i = threadIdx.x; i < G::OW * G::OH; i += NTHR) {
-            const int y = mm + i / G::OW, x = mm + i % G::OW;
-            sink(y, x, cur[y * G::SW + x], cur[G::PLANE + y * G::SW + x], cur[2 * G::PLANE + y * G::SW + x]);
-        }
-        return;
-    }
-    if (ITERS == 3) {
-        m += 3;
-        epf_stage<0, G, false, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
-        if (tc.edge) mirror_fixup<G, NTHR>(cur, m, G::R1 + G::R2, tc);
-        __syncthreads();
-    }
-    m += 2;
-    if (ITERS >= 2) {
-        epf_stage<1, G, false, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
-        if (tc.edge) mirror_fixup<G, NTHR>(cur, m, G::R2, tc);
-        __syncthreads();
-        m += 1;
-        epf_stage<2, G, true, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[2], sink);
-    } else {
-        epf_stage<1, G, true, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[1], sink);
-    }
-}
-
-#define JXL_RESTORE_BOUNDS(ITERS, PH) __launch_bounds__(512 / PH, ITERS == 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_WAVES) : PH == 1 ? 8 : 4)
-// occupancy floor: 8 waves per SIMD (64 VGPRs); the 3-iteration variant holds 48 tap distances per patch and spilled 130
-// VGPRs at that bound, so it is allowed 128 registers (4 waves per SIMD; its 43 KB tile allows 3 workgroups per CU anyway)
-template <bool GAB, int ITERS, bool PLAIN, int PH>
-__global__ JXL_RESTORE_BOUNDS(ITERS, PH) void k_restore_fused(const FusedArgs a) {
-    restore_fused_body<GAB, ITERS, PLAIN, PH>(a);
-}
-
-// a batch of frames in one launch (jxl_vardct_run_batch): blockIdx.y = frame, argument blocks in device memory read
-// through the constant address space (uniform scalar loads, as from the kernel-argument segment)
-template <bool GAB, int ITERS, bool PLAIN>
-__global__ JXL_RESTORE_BOUNDS(ITERS, 1) void k_restore_fused_batch(const FusedArgs* __restrict__ args) {
-    typedef const __attribute__((address_space(4))) FusedArgs* cargs;
-    restore_fused_body<GAB, ITERS, PLAIN, 1>(*(const FusedArgs*)((cargs)args + blockIdx.y));
-}
-
-template <bool GAB, int ITERS, bool PLAIN, int PH>
-void launch_tph(const FusedArgs& a, hipStream_t s) {
-    using G = Geo<GAB, ITERS>;
-    // experiment knob: extra dynamic LDS per workgroup caps the workgroups per CU (160 KiB / size), leaving wave slots to
-    // the latency-bound IDCT kernels of other frames in a batch
-    static const size_t pad = getenv("JXL_RESTORE_LDS_PAD") ? (size_t)atoi(getenv("JXL_RESTORE_LDS_PAD")) : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused<GAB, ITERS, PLAIN, PH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::LDS_BYTES + pad));
-        attr_set = true;
-    }
-    const int tiles_x = (a.W + G::OW - 1) / G::OW, tiles_y = (a.H + G::OH - 1) / G::OH;
-    if (a.ring_only) {
-        // tiles that intersect the ring of G::RT pixels along the frame edges
-        FusedArgs r = a;
-        r.ring_tx = (a.W - G::RT) / G::OW;
-        r.ring_ty = (a.H - G::RT) / G::OH;
-        const int nTB = r.ring_ty > 0 ? 1 + tiles_y - r.ring_ty : tiles_y;
-        const int nLR = r.ring_tx > 0 ? 1 + tiles_x - r.ring_tx : tiles_x;
-        const int mid = r.ring_ty > 0 ? r.ring_ty - 1 : 0;
-        const dim3 grid(tiles_x * nTB + mid * nLR);
-        hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, r);
-        return;
-    }
-    const int n_tiles = tiles_x * tiles_y;
-    const dim3 grid(((n_tiles + 7) / 8) * 8);
-    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, PLAIN, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, a);
-}
-template <bool GAB, int ITERS, bool PLAIN>
-void launch_tp(const FusedArgs& a, hipStream_t s) {
-    // 4x1 patches on 512 threads everywhere: twice the waves per CU of 4x2 patches for the same LDS footprint. The
-    // 3-iteration variant used to run 4x2 patches (fewer tap loads for its 13-tap first iteration) but spilled 169 VGPRs
-    // there: 841 us per 4K frame against 259 us with 4x1 patches and a 128-register budget (JXL_RESTORE_PH=2 selects 4x2)
-    static const int ph_env = getenv("JXL_RESTORE_PH") ? atoi(getenv("JXL_RESTORE_PH")) : 0;
-    if (ph_env == 2) launch_tph<GAB, ITERS, PLAIN, 2>(a, s);
-    else launch_tph<GAB, ITERS, PLAIN, 1>(a, s);
-}
-
-template <bool GAB, int ITERS>
-void launch_t(const FusedArgs& a, hipStream_t s) {
-    if (a.p.transfer == JXL_TRANSFER_NONE && a.p.max_value == 0) launch_tp<GAB, ITERS, true>(a, s);
-    else launch_tp<GAB, ITERS, false>(a, s);
-}
-
-}  // namespace
 
 bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                              const int32_t* sharpness, const RestoreParams& p, FusedArgs& a) {
@@ -741,52 +27,17 @@ bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h
     return true;
 }
 
-namespace {
-template <bool GAB, int ITERS, bool PLAIN>
-void launch_batch_t(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s) {
-    using G = Geo<GAB, ITERS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_restore_fused_batch<GAB, ITERS, PLAIN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        attr_set = true;
-    }
-    int max_tiles = 0;
-    for (int i = 0; i < n; i++)
-        max_tiles = std::max(max_tiles, ((host_args[i].W + G::OW - 1) / G::OW) * ((host_args[i].H + G::OH - 1) / G::OH));
-    const dim3 grid(((max_tiles + 7) / 8) * 8, n);
-    hipLaunchKernelGGL((k_restore_fused_batch<GAB, ITERS, PLAIN>), grid, dim3(512), G::LDS_BYTES, s, dev_args);
-}
-template <bool GAB, int ITERS>
-void launch_batch_i(const FusedArgs* h, const FusedArgs* d, int n, bool plain, hipStream_t s) {
-    if (plain) launch_batch_t<GAB, ITERS, true>(h, d, n, s);
-    else launch_batch_t<GAB, ITERS, false>(h, d, n, s);
-}
-}  // namespace
 
-// the kernel variant a frame's arguments select: Gaborish on/off, EPF iterations, plain float output or transfer / quantise
-int restore_fused_variant(const FusedArgs& a) {
-    const bool plain = a.p.transfer == JXL_TRANSFER_NONE && a.p.max_value == 0;
-    return (a.p.gab ? 8 : 0) | (a.p.epf_iters & 3) << 1 | (plain ? 1 : 0);
-}
+// which kernel instantiation the arguments select: Gaborish on/off, EPF iterations, sink kind
+int restore_fused_variant(const FusedArgs& a) { return (a.p.gab ? 32 : 0) | (a.p.epf_iters & 3) << 3 | sink_kind_of(a.p); }
 
 // host_args: the n frames' argument blocks (all of one variant), dev_args: the same blocks in device memory
 void launch_restore_fused_batch(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s) {
     if (n <= 0) return;
-    const int v = restore_fused_variant(host_args[0]);
-    const bool plain = v & 1, gab = (v & 8) != 0;
-    const int it = (v >> 1) & 3;
-    if (gab) {
-        if (it == 0) launch_batch_i<true, 0>(host_args, dev_args, n, plain, s);
-        else if (it == 1) launch_batch_i<true, 1>(host_args, dev_args, n, plain, s);
-        else if (it == 2) launch_batch_i<true, 2>(host_args, dev_args, n, plain, s);
-        else launch_batch_i<true, 3>(host_args, dev_args, n, plain, s);
-    } else {
-        if (it == 0) launch_batch_i<false, 0>(host_args, dev_args, n, plain, s);
-        else if (it == 1) launch_batch_i<false, 1>(host_args, dev_args, n, plain, s);
-        else if (it == 2) launch_batch_i<false, 2>(host_args, dev_args, n, plain, s);
-        else launch_batch_i<false, 3>(host_args, dev_args, n, plain, s);
-    }
+    const int sk = sink_kind_of(host_args[0].p);
+    if (sk == SK_PLAIN) launch_fused_batch_sk<SK_PLAIN>(host_args, dev_args, n, s);
+    else if (sk == SK_GENERIC) launch_restore_fused_gen(nullptr, host_args, dev_args, n, s);
+    else launch_restore_fused_q(sk, nullptr, host_args, dev_args, n, s);
 }
 
 bool launch_restore_fused(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
@@ -798,17 +49,33 @@ bool launch_restore_fused(const float* const in[3], void* const out[3], int h, i
         launch_restore_stream(a, s);
         a.ring_only = 1;
     }
-    const int it = p.epf_iters;
-    if (p.gab) {
-        if (it == 0) launch_t<true, 0>(a, s);
-        else if (it == 1) launch_t<true, 1>(a, s);
-        else if (it == 2) launch_t<true, 2>(a, s);
-        else launch_t<true, 3>(a, s);
+    const int sk = sink_kind_of(p);
+    if (sk == SK_PLAIN) {
+        // 4x1 patches on 512 threads everywhere: twice the waves per CU of 4x2 patches for the same LDS footprint. The
+        // 3-iteration variant used to run 4x2 patches (fewer tap loads for its 13-tap first iteration) but spilled 169 VGPRs
+        // there: 841 us per 4K frame against 259 us with 4x1 patches and a 128-register budget (JXL_RESTORE_PH=2 selects 4x2,
+        // float planes only)
+        static const int ph_env = getenv("JXL_RESTORE_PH") ? atoi(getenv("JXL_RESTORE_PH")) : 0;
+        if (ph_env == 2) {
+            const int it = p.epf_iters;
+            if (p.gab) {
+                if (it == 0) launch_tph<true, 0, SK_PLAIN, 2>(a, s);
+                else if (it == 1) launch_tph<true, 1, SK_PLAIN, 2>(a, s);
+                else if (it == 2) launch_tph<true, 2, SK_PLAIN, 2>(a, s);
+                else launch_tph<true, 3, SK_PLAIN, 2>(a, s);
+            } else {
+                if (it == 0) launch_tph<false, 0, SK_PLAIN, 2>(a, s);
+                else if (it == 1) launch_tph<false, 1, SK_PLAIN, 2>(a, s);
+                else if (it == 2) launch_tph<false, 2, SK_PLAIN, 2>(a, s);
+                else launch_tph<false, 3, SK_PLAIN, 2>(a, s);
+            }
+        } else {
+            launch_fused_sk<SK_PLAIN>(a, s);
+        }
+    } else if (sk == SK_GENERIC) {
+        launch_restore_fused_gen(&a, nullptr, nullptr, 0, s);
     } else {
-        if (it == 0) launch_t<false, 0>(a, s);
-        else if (it == 1) launch_t<false, 1>(a, s);
-        else if (it == 2) launch_t<false, 2>(a, s);
-        else launch_t<false, 3>(a, s);
+        launch_restore_fused_q(sk, &a, nullptr, nullptr, 0, s);
     }
     return true;
 }

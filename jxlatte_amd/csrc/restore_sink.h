@@ -43,8 +43,32 @@ __device__ __forceinline__ void sink_colour(const XybParams& xp, float& v0, floa
     v2 = xp.sm[6] * mixL + xp.sm[7] * mixM + xp.sm[8] * mixS;
 }
 
+// ---- sink kinds: what the fused restoration kernels are instantiated for (r4). SK_GENERIC picks transfer function and output
+// format per sample at run time (uniform compares and branches around every store: SALU 4.3x the float-plane variant, r3
+// counters); the others fix both at compile time -- the formats the PNG writer and the u16 HDR path ask for
+// (PNGWriter.java:65,105-111: tf = hdr ? PQ : sRGB, 8 / 16 bit; ImageBuffer.java:129-147).
+enum SinkKind {
+    SK_PLAIN = 0,       // float planes, no transfer function
+    SK_GENERIC = 1,     // anything (run-time)
+    SK_PQ_U16 = 2,      // TF_PQ -> castToIntWithMax(65535), planar u16 (JXL_OUT_U16; BASELINE config C4)
+    SK_PQ_RGB16 = 3,    // the same, R,G,B interleaved (JXL_OUT_RGB16: the HDR PNG)
+    SK_SRGB_RGB8 = 4,   // TF_SRGB -> 255, interleaved bytes (JXL_OUT_RGB8: the 8-bit PNG)
+    SK_SRGB_RGB16 = 5,  // TF_SRGB -> 65535, interleaved u16
+    SK_COUNT = 6
+};
+// the kind a frame's parameters select (host side): a specialised kind only when its tables are there
+inline int sink_kind_of(const RestoreParams& p) {
+    if (p.transfer == JXL_TRANSFER_NONE && p.max_value == 0) return SK_PLAIN;
+#ifndef JXL_EXACT_POW
+    if (p.transfer == JXL_TRANSFER_PQ && p.max_value == 65535 && p.out_elem == 2 && p.pq_tab && p.pq16_thr) return p.interleaved ? SK_PQ_RGB16 : SK_PQ_U16;
+    if (p.transfer == JXL_TRANSFER_SRGB && p.max_value == 255 && p.out_elem == 1 && p.interleaved && p.srgb8_tab) return SK_SRGB_RGB8;
+    if (p.transfer == JXL_TRANSFER_SRGB && p.max_value == 65535 && p.out_elem == 2 && p.interleaved && p.srgb16_tab) return SK_SRGB_RGB16;
+#endif
+    return SK_GENERIC;
+}
+
 // transfer function + ImageBuffer.castToInt0 of one sample (max_value > 0): the threshold-table forms of jxl_fastpow.h where the
-// output format has one (the reference's integer for every input), else the float transfer and the Java cast
+// output format has one (the oracle's integer for every input), else the float transfer and the Java cast
 __device__ __forceinline__ int32_t sink_quant(const FusedArgs& a, float t) {
 #ifndef JXL_EXACT_POW
     if (a.p.transfer == JXL_TRANSFER_PQ && a.p.max_value == 65535 && a.p.pq_tab && a.p.pq16_thr)
@@ -62,67 +86,111 @@ __device__ __forceinline__ int32_t sink_quant(const FusedArgs& a, float t) {
     const int32_t q = sink_f2i_java(t * (float)a.p.max_value + 0.5f);
     return q < 0 ? 0 : q > a.p.max_value ? a.p.max_value : q;
 }
+// the same for a sink kind known at compile time
+template <int SK>
+__device__ __forceinline__ int32_t sink_quant_k(const FusedArgs& a, float t) {
+    if constexpr (SK == SK_PQ_U16 || SK == SK_PQ_RGB16) return fp_pq16(t, reinterpret_cast<const float4*>(a.p.pq_tab), a.p.pq16_thr);
+    else if constexpr (SK == SK_SRGB_RGB8) return fp_srgb8(t, reinterpret_cast<const float4*>(a.p.srgb8_tab));
+    else if constexpr (SK == SK_SRGB_RGB16)
+        return fp_srgb16(t, reinterpret_cast<const float4*>(a.p.srgb16_tab), a.p.srgb16_tab + kSrgb8TableFloats);
+    else return sink_quant(a, t);
+}
 
-// pixel g (= y * W + x) of the frame; PLAIN: float planes, no transfer function
-template <bool PLAIN>
-__device__ __forceinline__ void sink_store(const FusedArgs& a, uint32_t g, float v0, float v1, float v2) {
+// pixel g (= y * W + x) of the frame
+template <int SK>
+__device__ __forceinline__ void sink_store_k(const FusedArgs& a, uint32_t g, float v0, float v1, float v2) {
     float v[3] = {v0, v1, v2};
-    if (PLAIN) {
+    if constexpr (SK == SK_PLAIN) {
 #pragma unroll
         for (int c = 0; c < 3; c++) ((float*)a.out[c])[g] = v[c];
         return;
-    }
-    if (a.p.max_value > 0) {
+    } else if constexpr (SK == SK_PQ_U16) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) ((uint16_t*)a.out[c])[g] = (uint16_t)sink_quant_k<SK>(a, v[c]);
+        return;
+    } else if constexpr (SK == SK_PQ_RGB16 || SK == SK_SRGB_RGB16) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)sink_quant_k<SK>(a, v[c]);
+        return;
+    } else if constexpr (SK == SK_SRGB_RGB8) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)sink_quant_k<SK>(a, v[c]);
+        return;
+    } else {
+        if (a.p.max_value > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int32_t q = sink_quant(a, v[c]);
+                if (a.p.interleaved) {  // R,G,B per pixel in out[0] (PNGWriter.writeIDAT order)
+                    if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
+                    else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
+                } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
+                else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
+                else ((int32_t*)a.out[c])[g] = q;
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int32_t q = sink_quant(a, v[c]);
-            if (a.p.interleaved) {  // R,G,B per pixel in out[0] (PNGWriter.writeIDAT order)
-                if (a.p.out_elem == 2) ((uint16_t*)a.out[0])[3 * g + c] = (uint16_t)q;
-                else ((uint8_t*)a.out[0])[3 * g + c] = (uint8_t)q;
-            } else if (a.p.out_elem == 2) ((uint16_t*)a.out[c])[g] = (uint16_t)q;
-            else if (a.p.out_elem == 1) ((uint8_t*)a.out[c])[g] = (uint8_t)q;
-            else ((int32_t*)a.out[c])[g] = q;
-        }
-        return;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float t = v[c];
+            float t = v[c];
 #ifndef JXL_EXACT_POW
-        if (a.p.transfer == JXL_TRANSFER_PQ && a.p.pq_tab) t = fp_tf_pq_tab(t, reinterpret_cast<const float4*>(a.p.pq_tab));
-        else
+            if (a.p.transfer == JXL_TRANSFER_PQ && a.p.pq_tab) t = fp_tf_pq_tab(t, reinterpret_cast<const float4*>(a.p.pq_tab));
+            else
 #endif
-        if (a.p.transfer == JXL_TRANSFER_PQ) t = sink_tf_pq(t);
-        else if (a.p.transfer == JXL_TRANSFER_SRGB) t = sink_tf_srgb(t);
-        ((float*)a.out[c])[g] = t;
+            if (a.p.transfer == JXL_TRANSFER_PQ) t = sink_tf_pq(t);
+            else if (a.p.transfer == JXL_TRANSFER_SRGB) t = sink_tf_srgb(t);
+            ((float*)a.out[c])[g] = t;
+        }
     }
 }
+// (the register-streaming kernel's two forms)
+template <bool PLAIN>
+__device__ __forceinline__ void sink_store(const FusedArgs& a, uint32_t g, float v0, float v1, float v2) {
+    sink_store_k<PLAIN ? SK_PLAIN : SK_GENERIC>(a, g, v0, v1, v2);
+}
 
-// four consecutive pixels of a row into an interleaved 8-bit buffer (JXL_OUT_RGB8), g even (tile origins are multiples of 62, patch
-// columns of 4; the frame width is a multiple of 8): the 12 bytes leave as three dwords when 3 * g is a multiple of 4 bytes, as
-// 2 + 4 + 4 + 2 bytes otherwise, instead of twelve byte stores
-__device__ __forceinline__ void sink_store_rgb8x4(const FusedArgs& a, uint32_t g, const float o[3][4]) {
-    uint32_t w[3] = {0u, 0u, 0u};
+struct __attribute__((packed, aligned(8))) sink_f4a8 {
+    float x, y, z, w;
+};
+struct __attribute__((packed, aligned(4))) sink_u2a4 {
+    uint32_t x, y;
+};
+struct __attribute__((packed, aligned(4))) sink_u4a4 {
+    uint32_t x, y, z, w;
+};
+// pixels g .. g+3 of a row, g even, as the kind's wide stores; false: the kind has none (the caller stores pixel by pixel)
+template <int SK>
+__device__ __forceinline__ bool sink_store4_k(const FusedArgs& a, uint32_t g, const float o[3][4]) {
+    if constexpr (SK == SK_PLAIN) {
+        // one 16-byte store per lane and channel: a wave instruction then covers whole rows of 256 contiguous bytes instead of
+        // every other 8 bytes (g even: 8-byte aligned, so the store is declared 8-byte aligned; gfx950 global stores do not need
+        // 16-byte alignment)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int c = 0; c < 3; c++) *reinterpret_cast<sink_f4a8*>((float*)a.out[c] + g) = sink_f4a8{o[c][0], o[c][1], o[c][2], o[c][3]};
+        return true;
+    } else if constexpr (SK == SK_PQ_U16) {
+        // four u16 of a plane = 8 bytes at a 4-byte-aligned address
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const uint32_t q = (uint32_t)sink_quant(a, o[c][i]);
-            const int k = 3 * i + c;
-            w[k >> 2] |= q << (8 * (k & 3));
+            uint32_t q[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) q[i] = (uint32_t)sink_quant_k<SK>(a, o[c][i]);
+            *reinterpret_cast<sink_u2a4*>((uint16_t*)a.out[c] + g) = sink_u2a4{q[0] | q[1] << 16, q[2] | q[3] << 16};
         }
-    uint8_t* d8 = (uint8_t*)a.out[0] + 3 * (size_t)g;
-    if ((g & 3u) == 0) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(d8);
-        d[0] = w[0];
-        d[1] = w[1];
-        d[2] = w[2];
-    } else {  // g = 2 (mod 4): the byte offset is 2 (mod 4)
-        *reinterpret_cast<uint16_t*>(d8) = (uint16_t)(w[0] & 0xffffu);
-        uint32_t* d = reinterpret_cast<uint32_t*>(d8 + 2);
-        d[0] = (w[0] >> 16) | (w[1] << 16);
-        d[1] = (w[1] >> 16) | (w[2] << 16);
-        *reinterpret_cast<uint16_t*>(d8 + 10) = (uint16_t)(w[2] >> 16);
+        return true;
+    } else if constexpr (SK == SK_PQ_RGB16 || SK == SK_SRGB_RGB16) {
+        // twelve u16 = 24 contiguous bytes at 6 g: a multiple of 12, 4-byte aligned
+        uint32_t q[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) q[3 * i + c] = (uint32_t)sink_quant_k<SK>(a, o[c][i]);
+        uint16_t* d = (uint16_t*)a.out[0] + 3 * (size_t)g;
+        *reinterpret_cast<sink_u4a4*>(d) = sink_u4a4{q[0] | q[1] << 16, q[2] | q[3] << 16, q[4] | q[5] << 16, q[6] | q[7] << 16};
+        *reinterpret_cast<sink_u2a4*>(d + 8) = sink_u2a4{q[8] | q[9] << 16, q[10] | q[11] << 16};
+        return true;
+    } else {
+        return false;  // RGB8: twelve byte stores measured faster than three packed dwords (r3, JXL_RGB8_PACKED); generic: per pixel
     }
 }
 

@@ -308,7 +308,7 @@ def test_device_decode_matches_oracle_decode(device_backend, oracle_backend, nam
     PNGWriter(exp).write(gb)
     pa, _ = read_png(ga.getvalue())
     pb, _ = read_png(gb.getvalue())
-    assert np.abs(pa.astype(np.int32) - pb.astype(np.int32)).max() <= 1  # transfer stage: 1 ulp -> at most one code value
+    assert np.array_equal(pa, pb)  # the sRGB transfer + quantisation of the device equals the oracle's for every input (r3 tables)
 
 
 # ---- large reference samples (not committed: tests/golden/samples_large/ is git-ignored but travels with gpurun) -------
