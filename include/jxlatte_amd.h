@@ -217,6 +217,16 @@ jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* ctx, int16_t* planes[3], int32_t s
  * rows[c] * strides[c] samples. The JNI shim sizes its direct ByteBuffers from this, never from a caller-supplied count. */
 jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* ctx, int32_t rows[3]);
 jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* ctx);
+/* The same pair without the zero-fill (r4): a decoder writes EVERY sample of every group it decodes (HFCoefficients.java:76-138
+ * leaves the untouched samples of its fresh int[][] at zero -- the caller of this form stores those zeros itself, or keeps its
+ * own cleared scratch and copies whole groups), so map's 50 MB of host stores per 4K frame are wasted on it. With
+ * JXL_MAP_NO_FILL the planes come back as they are; commit_..._groups names the groups whose rectangles the caller has fully
+ * written (group_written[g] != 0, g in Frame group order, n_groups = all groups of the frame); every other group reads as zero
+ * (its rectangle is cleared in the staging buffer before the transfer). map also no longer waits for the context's whole
+ * stream, only for the previous commit's transfers to have read the buffer. */
+#define JXL_MAP_NO_FILL 1
+jxl_status jxl_vardct_map_coeffs_i16_ex(jxl_ctx* ctx, int16_t* planes[3], int32_t strides[3], int32_t flags);
+jxl_status jxl_vardct_commit_coeffs_i16_groups(jxl_ctx* ctx, const uint8_t* group_written, int32_t n_groups);
 /* Page-locked host memory for the buffers that cross the bus (coefficient planes in, pixel planes out; a JNI caller wraps it
  * with NewDirectByteBuffer). put_group / put_group_i16 / read_output recognise such pointers: the copy is a direct DMA at
  * bus speed instead of the runtime's staged copy out of pageable memory, and put_group returns without waiting for it
@@ -245,6 +255,13 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n);
 jxl_status jxl_vardct_finish_frame(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
 /* copy the last run's result planes (device) to host without re-running */
 jxl_status jxl_vardct_read_output(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
+/* read_output in two halves (r4): _begin queues the device-to-host copies behind the frame's kernels and returns, _wait blocks
+ * until they have landed. In between the host may drive the NEXT frame of this context (begin_frame ... commit ... run: its
+ * device work queues behind the copies), which is how one context overlaps the host's share of frame n+1 with the device's share
+ * of frame n -- what the reference's one-frame-at-a-time loop (JXLCodestreamDecoder.decode, :506-720) leaves on the table. The
+ * destination must stay valid until _wait and should be page-locked (jxl_host_alloc) for the copy to be a queued DMA. */
+jxl_status jxl_vardct_read_output_begin(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
+jxl_status jxl_vardct_read_output_wait(jxl_ctx* ctx);
 /* ---- the frame's colour planes kept on the device between the stages that follow decodeFrame --------------------------
  * JXLCodestreamDecoder.decode runs, on the frame's own buffers and in this order (JXLCodestreamDecoder.java:628-637):
  * Frame.upsample, Frame.initializeNoise, computePatches, Frame.renderSplines, Frame.synthesizeNoise,

@@ -47,6 +47,9 @@ public final class NativeBackend implements AutoCloseable {
     public native ByteBuffer[] mapCoeffsI16();                     // jxl_vardct_map_coeffs_i16 + jxl_vardct_coeff_plane_rows + NewDirectByteBuffer
     public native int[] coeffPlaneRows();                          // jxl_vardct_coeff_plane_rows -> rows of the three mapped planes
     public native void commitCoeffsI16();                          // jxl_vardct_commit_coeffs_i16
+    /** the same planes without the zero-fill: the decoder writes every sample of the groups it then names in commitCoeffsI16Groups */
+    public native ByteBuffer[] mapCoeffsI16NoFill();               // jxl_vardct_map_coeffs_i16_ex(JXL_MAP_NO_FILL)
+    public native void commitCoeffsI16Groups(byte[] groupWritten); // jxl_vardct_commit_coeffs_i16_groups
     /** Page-locked direct buffers for planes that cross the bus (coefficients in, pixels out). */
     public static native ByteBuffer hostAlloc(long bytes);         // jxl_host_alloc + NewDirectByteBuffer
     public static native void hostFree(ByteBuffer b);              // jxl_host_free(GetDirectBufferAddress(b))
@@ -55,6 +58,9 @@ public final class NativeBackend implements AutoCloseable {
      *  on its context's stream, readOutput() waits for it. runBatch hands several prepared frames to one call. */
     public native void run();                                      // jxl_vardct_run
     public native void readOutput(ByteBuffer outX, ByteBuffer outY, ByteBuffer outB, long stride); // jxl_vardct_read_output
+    /** readOutput in two halves: between them the host may drive the next frame of this context (buffers from hostAlloc) */
+    public native void readOutputBegin(ByteBuffer outX, ByteBuffer outY, ByteBuffer outB, long stride); // jxl_vardct_read_output_begin
+    public native void readOutputWait();                                                           // jxl_vardct_read_output_wait
     public static void runBatch(NativeBackend[] frames) {          // jxl_vardct_run_batch
         long[] h = new long[frames.length];
         for (int i = 0; i < frames.length; i++) h[i] = frames[i].ctx;

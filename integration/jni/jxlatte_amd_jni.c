@@ -145,6 +145,38 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_commitCoeff
     CHECK(jxl_vardct_commit_coeffs_i16(c));
 }
 
+/* the same planes without the zero-fill (JXL_MAP_NO_FILL): the decoder writes every sample of the groups it then names */
+JNIEXPORT jobjectArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_mapCoeffsI16NoFill(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    int16_t* pl[3];
+    int32_t st[3], rows[3];
+    jxl_status r = jxl_vardct_map_coeffs_i16_ex(c, pl, st, JXL_MAP_NO_FILL);
+    if (r == JXL_OK) r = jxl_vardct_coeff_plane_rows(c, rows);
+    if (r) { rethrow(e, c, r); return NULL; }
+    jclass bb = (*e)->FindClass(e, "java/nio/ByteBuffer");
+    if (!bb) return NULL;  /* exception pending */
+    jobjectArray out = (*e)->NewObjectArray(e, 3, bb, NULL);
+    if (!out) return NULL;
+    for (int i = 0; i < 3; i++) {
+        jobject b = (*e)->NewDirectByteBuffer(e, pl[i], (jlong)st[i] * rows[i] * 2);
+        if (!b || (*e)->ExceptionCheck(e)) return NULL;
+        (*e)->SetObjectArrayElement(e, out, i, b);
+    }
+    return out;
+}
+
+/* written: one byte per group of the frame (non-zero = its rectangle was fully written); the length is checked by the library */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_commitCoeffsI16Groups(JNIEnv* e, jobject self, jbyteArray written) {
+    jxl_ctx* c = ctx_of(e, self);
+    if (!written) { rethrow(e, c, JXL_ERR_INVALID_ARGUMENT); return; }
+    const jsize n = (*e)->GetArrayLength(e, written);
+    jbyte* w = (*e)->GetByteArrayElements(e, written, NULL);
+    if (!w) return;  /* OutOfMemoryError pending */
+    const jxl_status r = jxl_vardct_commit_coeffs_i16_groups(c, (const uint8_t*)w, (int32_t)n);
+    (*e)->ReleaseByteArrayElements(e, written, w, JNI_ABORT);
+    if (r) rethrow(e, c, r);
+}
+
 JNIEXPORT jobject JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_hostAlloc(JNIEnv* e, jclass k, jlong bytes) {
     void* p = jxl_host_alloc((size_t)bytes);
     return p ? (*e)->NewDirectByteBuffer(e, p, bytes) : NULL;
@@ -171,6 +203,19 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(
     jxl_ctx* c = ctx_of(e, self);
     void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
     CHECK(jxl_vardct_read_output(c, out, stride));
+}
+
+/* readOutput in two halves: the host drives the next frame of this context between them (direct buffers from hostAlloc) */
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutputBegin(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
+        jlong stride) {
+    jxl_ctx* c = ctx_of(e, self);
+    void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
+    CHECK(jxl_vardct_read_output_begin(c, out, stride));
+}
+
+JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutputWait(JNIEnv* e, jobject self) {
+    jxl_ctx* c = ctx_of(e, self);
+    CHECK(jxl_vardct_read_output_wait(c));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_prepare(JNIEnv* e, jobject self) {

@@ -71,6 +71,8 @@ SIGNATURES = {
     "jxl_vardct_map_coeffs_i16": (i32, [vp, C.POINTER(C.POINTER(C.c_int16)), pi]),
     "jxl_vardct_coeff_plane_rows": (i32, [vp, pi]),
     "jxl_vardct_commit_coeffs_i16": (i32, [vp]),
+    "jxl_vardct_map_coeffs_i16_ex": (i32, [vp, C.POINTER(C.POINTER(C.c_int16)), pi, i32]),
+    "jxl_vardct_commit_coeffs_i16_groups": (i32, [vp, C.POINTER(C.c_uint8), i32]),
     "jxl_host_alloc": (vp, [C.c_size_t]),
     "jxl_host_free": (None, [vp]),
     "jxl_vardct_prepare": (i32, [vp]),
@@ -78,6 +80,8 @@ SIGNATURES = {
     "jxl_vardct_run_batch": (i32, [C.POINTER(C.c_void_p), i32]),
     "jxl_vardct_finish_frame": (i32, [vp, pv3, i64]),
     "jxl_vardct_read_output": (i32, [vp, pv3, i64]),
+    "jxl_vardct_read_output_begin": (i32, [vp, pv3, i64]),
+    "jxl_vardct_read_output_wait": (i32, [vp]),
     "jxl_vardct_copy_output_device": (i32, [vp, vp]),
     "jxl_planes_from_frame": (i32, [vp, i32, i32]),
     "jxl_planes_upsample": (i32, [vp, i32, pf]),

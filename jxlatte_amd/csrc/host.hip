@@ -24,20 +24,29 @@ namespace {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool own = true;  // false: a view into another allocation (the per-frame table arena)
     bool ensure(size_t bytes) {
-        if (bytes <= cap && p) return true;
-        if (p) (void)hipFree(p);
+        if (bytes <= cap && p && own) return true;
+        if (p && own) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        own = true;
         if (bytes == 0) bytes = 16;
         if (hipMalloc(&p, bytes) != hipSuccess) return false;
         cap = bytes;
         return true;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && own) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        own = true;
+    }
+    void view(void* q, size_t bytes) {
+        if (p && own) (void)hipFree(p);
+        p = q;
+        cap = bytes;
+        own = false;
     }
     template <typename T>
     T* as() const { return reinterpret_cast<T*>(p); }
@@ -100,6 +109,18 @@ struct PinnedAlloc {
 template <class T>
 using pinned_vector = std::vector<T, PinnedAlloc<T>>;
 
+// a typed window of the table staging buffer (jxl_ctx::h_tab)
+template <class T>
+struct HSpan {
+    T* p = nullptr;
+    size_t n = 0;
+    T& operator[](size_t i) const { return p[i]; }
+    T* data() const { return p; }
+    T* begin() const { return p; }
+    T* end() const { return p + n; }
+    size_t size() const { return n; }
+};
+
 struct jxl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -115,11 +136,23 @@ struct jxl_ctx {
     DevBuf coeff[3], lf[3], llf[3], weights_t, hf_mul, sharp, xfy, bfy, weights, planeA[3], planeB[3], outbuf[3], inv_sigma, blocks, items,
         group_tmp, bad_flag;
     int32_t woffs[51]{};
-    pinned_vector<int32_t> h_hf_mul, h_sharp;
+    // Per-frame tables (r4): ONE page-locked staging buffer laid out like ONE device arena, ONE transfer per prepare. The
+    // fixed-size grids (hfMultiplier, sharpness, CfL factors per tile, LF planes: sizes known at begin_frame) come first and the
+    // host writes them in place (set_lfgroup); the block records and item lists follow (finalize_tables). The transfer is queued
+    // and an event is recorded; the host waits for it only before it writes the staging buffer again. Until r3: nine transfers
+    // (two of them synchronous) from nine buffers and a stream synchronisation, 0.41 ms of a 1.2 ms prepare.
+    char* h_tab = nullptr;
+    size_t h_tab_cap = 0;
+    bool h_tab_pinned = false;
+    DevBuf tab;
+    hipEvent_t tab_ev = nullptr;
+    bool tab_inflight = false;
+    size_t tab_fixed = 0, off_hfm = 0, off_sharp = 0, off_kx = 0, off_kb = 0, off_lf[3] = {0, 0, 0};
+    HSpan<int32_t> h_hf_mul, h_sharp;
     std::vector<int32_t> h_xfy, h_bfy;
-    pinned_vector<float> h_kx, h_kb;
+    HSpan<float> h_kx, h_kb;
     std::vector<uint8_t> h_sel;
-    pinned_vector<float> h_lf[3];
+    HSpan<float> h_lf[3];
     int32_t sharp_bad = 0;       // first EPF sharpness outside 0..7 seen by finalize_tables (Frame.java:565-566), or 0
     bool sharp_is_bad = false;
     std::vector<std::vector<DevBlock>> lfg_blocks;  // per LF group, reference order, frame coordinates
@@ -163,6 +196,11 @@ struct jxl_ctx {
     DevBuf batch_wg3_args;
     bool coeff16_resident = false;  // stage16 holds the whole frame's committed int16 planes and nothing was put since (JXL_WG3_I16)
     void* h_map16 = nullptr;   // page-locked frame-sized int16 planes handed to the caller (jxl_vardct_map_coeffs_i16)
+    bool map16_nofill = false;       // mapped without zero-fill: commit must be told which groups were written
+    hipEvent_t map16_ev = nullptr;   // "the commit's transfers have read h_map16": what the next map waits for (not the whole stream)
+    bool map16_inflight = false;
+    hipEvent_t out_ev = nullptr;     // jxl_vardct_read_output_begin's copies
+    bool out_inflight = false;
     size_t h_map16_bytes = 0;
     bool map16_valid = false;
     DevBuf stage16;            // int16 wire format: one tile per (group, channel) (jxl_vardct_put_group_i16)
@@ -281,6 +319,69 @@ bool is_pinned_host(const void* p) {
 bool is_small(int t) { return JXL_TT[t].ph == 8 && JXL_TT[t].pw == 8; }
 bool is_large(int t) { return JXL_TT[t].ph >= 128 || JXL_TT[t].pw >= 128; }
 
+// ---- table staging buffer (jxl_ctx::h_tab) ----
+constexpr size_t kTabAlign = 256;
+inline size_t tab_up(size_t v) { return (v + kTabAlign - 1) & ~(kTabAlign - 1); }
+// the queued transfer of the staging buffer has finished reading it
+void tab_wait(jxl_ctx* c) {
+    if (c->tab_inflight && c->tab_ev) (void)hipEventSynchronize(c->tab_ev);
+    c->tab_inflight = false;
+}
+// at least `bytes` of staging, the first `keep` bytes preserved; grows geometrically and never shrinks (a page-locked
+// allocation costs milliseconds and hipHostFree synchronises the device)
+bool tab_reserve(jxl_ctx* c, size_t bytes, size_t keep) {
+    if (bytes <= c->h_tab_cap) return true;
+    tab_wait(c);
+    const size_t cap = std::max(bytes, c->h_tab_cap + c->h_tab_cap / 2);
+    void* q = nullptr;
+    bool pinned = true;
+    if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess || !q) {
+        (void)hipGetLastError();
+        static bool said = false;
+        if (!said && getenv("JXL_PREPARE_TIMING")) fprintf(stderr, "[prepare] page-locking %zu bytes failed: pageable staging\n", cap);
+        said = true;
+        q = malloc(cap);
+        pinned = false;
+        if (!q) return false;
+    }
+    if (keep && c->h_tab) memcpy(q, c->h_tab, std::min(keep, c->h_tab_cap));
+    if (c->h_tab) {
+        if (c->h_tab_pinned) (void)hipHostFree(c->h_tab);
+        else free(c->h_tab);
+    }
+    c->h_tab = static_cast<char*>(q);
+    c->h_tab_cap = cap;
+    c->h_tab_pinned = pinned;
+    return true;
+}
+// point the fixed-size grids at their sections
+void tab_bind_fixed(jxl_ctx* c, size_t nc, size_t nt) {
+    c->h_hf_mul = {reinterpret_cast<int32_t*>(c->h_tab + c->off_hfm), nc};
+    c->h_sharp = {reinterpret_cast<int32_t*>(c->h_tab + c->off_sharp), nc};
+    c->h_kx = {reinterpret_cast<float*>(c->h_tab + c->off_kx), nt};
+    c->h_kb = {reinterpret_cast<float*>(c->h_tab + c->off_kb), nt};
+    for (int i = 0; i < 3; i++) c->h_lf[i] = {reinterpret_cast<float*>(c->h_tab + c->off_lf[i]), nc};
+}
+// begin_frame: lay the fixed sections out, make room (plus a first guess for the block records), fill the defaults
+bool tab_begin_frame(jxl_ctx* c, size_t nc, size_t nt) {
+    size_t o = 0;
+    c->off_hfm = o; o = tab_up(o + 4 * nc);
+    c->off_sharp = o; o = tab_up(o + 4 * nc);
+    c->off_kx = o; o = tab_up(o + 4 * nt);
+    c->off_kb = o; o = tab_up(o + 4 * nt);
+    for (int i = 0; i < 3; i++) { c->off_lf[i] = o; o = tab_up(o + 4 * nc); }
+    c->tab_fixed = o;
+    tab_wait(c);  // the previous frame's transfer may still be reading the buffer
+    if (!tab_reserve(c, o + sizeof(DevBlock) * nc / 2 + 65536, 0)) return false;
+    tab_bind_fixed(c, nc, nt);
+    std::fill(c->h_hf_mul.begin(), c->h_hf_mul.end(), 1);
+    memset(c->h_sharp.data(), 0, 4 * nc);
+    memset(c->h_kx.data(), 0, 4 * nt);
+    memset(c->h_kb.data(), 0, 4 * nt);
+    for (int i = 0; i < 3; i++) memset(c->h_lf[i].data(), 0, 4 * nc);
+    return true;
+}
+
 // Bin the varblocks and compute the CfL cache-order masks; upload side tables.
 jxl_status finalize_tables(jxl_ctx* c) {
     if (!c->tables_dirty) return JXL_OK;
@@ -297,27 +398,26 @@ jxl_status finalize_tables(jxl_ctx* c) {
         if (!c->lfg_set[i]) return fail(c, JXL_ERR_STATE, "LF group %d was never set", i);
     if (!c->have_weights) return fail(c, JXL_ERR_STATE, "quant weights were never set");
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
-    // reference visiting order: groups in raster order (Frame.java:367-373), inside a group the LF group's
-    // blockList order filtered by the group (HFCoefficients.java:76-85)
-    // counting sort by group (stable: keeps the block-list order inside a group), and the per-type counts on the way
+    // Reference visiting order: groups in raster order (Frame.java:367-373), inside a group the LF group's blockList order
+    // filtered by the group (HFCoefficients.java:76-85). The per-type block lists are kept in that order (group-major: an item's
+    // blocks are neighbours in the frame). r4: two passes over the block lists instead of four (count by group, scatter by group,
+    // bin with push_back, concatenate) --
+    //   1. count per (group, type); the counts become the cursors of every (group, type) run inside the FINAL layout of h_blocks;
+    //   2. every block gets its CfL mask and hfMultiplier and goes straight to its slot.
+    // Pass 2 walks the LF groups' lists as they are. That is enough for the masks: a 64x64 tile lies in one group, only ONE block
+    // contains its origin, and the mask bit of (block, tile) asks whether that block was visited earlier IN THE SAME GROUP --
+    // the filtered list order, which the LF group's list order preserves.
     const int n_groups = grs * gcs;
-    std::vector<uint32_t> g_off((size_t)n_groups + 1, 0);
-    size_t t_count[JXL_NUM_TRANSFORM_TYPES] = {};
+    constexpr int NTY = JXL_NUM_TRANSFORM_TYPES;
+    size_t t_count[NTY] = {};
     size_t n_all = 0;
+    std::vector<uint32_t> cur((size_t)n_groups * NTY, 0);
     for (int li = 0; li < lrs * lcs; li++) {
         n_all += c->lfg_blocks[li].size();
-        for (const DevBlock& b : c->lfg_blocks[li]) {
-            g_off[(size_t)((b.cy >> 5) * grs + (b.cx >> 5)) + 1]++;
-            t_count[b.type]++;
-        }
+        for (const DevBlock& b : c->lfg_blocks[li]) cur[(size_t)((b.cy >> 5) * grs + (b.cx >> 5)) * NTY + b.type]++;
     }
-    for (int g = 0; g < n_groups; g++) g_off[(size_t)g + 1] += g_off[g];
-    std::vector<DevBlock> by_group(n_all);
-    {
-        std::vector<uint32_t> pos(g_off.begin(), g_off.end() - 1);
-        for (int li = 0; li < lrs * lcs; li++)
-            for (const DevBlock& b : c->lfg_blocks[li]) by_group[pos[(size_t)((b.cy >> 5) * grs + (b.cx >> 5))]++] = b;
-    }
+    for (int g = 0; g < n_groups; g++)
+        for (int t = 0; t < NTY; t++) t_count[t] += cur[(size_t)g * NTY + t];
     // EPF sharpness range (Frame.java:565-566): found here, once per frame description; reported by jxl_vardct_run when the frame
     // runs the filter (it used to walk all cells on EVERY run)
     c->sharp_is_bad = false;
@@ -327,77 +427,76 @@ jxl_status finalize_tables(jxl_ctx* c) {
             c->sharp_bad = v;
             break;
         }
-    mark("blocks by group");
-    // The groups are independent here: a 64x64 tile lies in exactly one 256x256 group, so the `stamp` entries a group's blocks
-    // read and write are its own. JXL_PREPARE_THREADS=n lets n host threads each take a contiguous range of groups and bin into
-    // their own per-type lists (concatenated in thread order the lists are in group order again). Measured on the GPU box
-    // (256-core EPYC): 8 threads 0.70-0.74 ms against 0.44 ms single-threaded -- starting the threads costs more than the 60 000
-    // blocks of a 4K frame -- so the default is one thread.
-    std::vector<int32_t> stamp((size_t)c->th * c->tw, -1);
-    std::vector<DevBlock> sm[JXL_NUM_TRANSFORM_TYPES];
+    mark("counts");
+    // final layout of h_blocks: [8x8-footprint types..., medium types..., large types...] (what lay_out / the large-block path expect)
+    uint32_t first_of_all[NTY] = {};
     {
-        static const int n_thr_env = getenv("JXL_PREPARE_THREADS") ? atoi(getenv("JXL_PREPARE_THREADS")) : 0;
-        const int hw = (int)std::thread::hardware_concurrency();
-        const int n_thr = std::max(1, std::min({n_thr_env > 0 ? n_thr_env : 1, hw > 0 ? hw : 1, n_groups, n_all > 4096 ? 64 : 1}));
-        struct Part {
-            std::vector<DevBlock> sm[JXL_NUM_TRANSFORM_TYPES];
-            int err = 0;  // 1: block leaves the frame, 2: spans too many tiles
-            DevBlock bad{};
-        };
-        std::vector<Part> parts((size_t)n_thr);
-        for (Part& P : parts)
-            for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) P.sm[t].reserve(t_count[t] / (size_t)n_thr + (n_thr > 1 ? t_count[t] / 8 + 16 : 0));
-        auto work = [&](int t) {
-            Part& P = parts[(size_t)t];
-            const int g0 = (int)((int64_t)n_groups * t / n_thr), g1 = (int)((int64_t)n_groups * (t + 1) / n_thr);
-            for (int g = g0; g < g1 && !P.err; g++) {
-                for (uint32_t bi = g_off[g]; bi < g_off[(size_t)g + 1]; bi++) {
-                    DevBlock b = by_group[bi];
-                    const int ph = JXL_TT[b.type].ph, pw = JXL_TT[b.type].pw;
-                    const int py0 = b.cy * 8, px0 = b.cx * 8;
-                    if (py0 + ph > c->H || px0 + pw > c->W) { P.err = 1; P.bad = b; break; }
-                    const int ty0 = py0 >> 6, tx0 = px0 >> 6, ty1 = (py0 + ph - 1) >> 6, tx1 = (px0 + pw - 1) >> 6;
-                    if (ty1 - ty0 > 4 || tx1 - tx0 > 4) { P.err = 2; P.bad = b; break; }
-                    uint32_t mask = 0;
+        uint32_t o = 0;
+        for (int pass = 0; pass < 3; pass++)
+            for (int t = 0; t < NTY; t++) {
+                const int cls = is_large(t) ? 2 : is_small(t) ? 0 : 1;
+                if (cls != pass) continue;
+                first_of_all[t] = o;
+                o += (uint32_t)t_count[t];
+            }
+    }
+    for (int t = 0; t < NTY; t++) {
+        uint32_t o = first_of_all[t];
+        for (int g = 0; g < n_groups; g++) {
+            const uint32_t n = cur[(size_t)g * NTY + t];
+            cur[(size_t)g * NTY + t] = o;
+            o += n;
+        }
+    }
+    c->h_blocks.resize(n_all);
+    {
+        std::vector<int32_t> stamp((size_t)c->th * c->tw, -1);
+        DevBlock* out = c->h_blocks.data();
+        for (int li = 0; li < lrs * lcs; li++)
+            for (const DevBlock& b0 : c->lfg_blocks[li]) {
+                DevBlock b = b0;
+                const int g = (b.cy >> 5) * grs + (b.cx >> 5);
+                const int ph = JXL_TT[b.type].ph, pw = JXL_TT[b.type].pw;
+                const int py0 = b.cy * 8, px0 = b.cx * 8;
+                if (py0 + ph > c->H || px0 + pw > c->W)
+                    return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock (%d,%d) type %u leaves the frame", b.cy, b.cx, b.type);
+                const int ty0 = py0 >> 6, tx0 = px0 >> 6, ty1 = (py0 + ph - 1) >> 6, tx1 = (px0 + pw - 1) >> 6;
+                if (ty1 - ty0 > 4 || tx1 - tx0 > 4) return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock spans too many tiles");
+                uint32_t mask = 0;
+                if (ty0 == ty1 && tx0 == tx1) {  // one tile (every 8x8 block: five blocks in six of a photographic frame)
+                    int32_t& sp = stamp[(size_t)ty0 * c->tw + tx0];
+                    if (!((py0 | px0) & 63)) sp = g;
+                    else if (sp != g) mask = 1u;
+                } else {
                     for (int ty = ty0; ty <= ty1; ty++)
                         for (int tx = tx0; tx <= tx1; tx++) {
                             const bool origin_inside = ty * 64 >= py0 && tx * 64 >= px0;  // (< py0+ph, px0+pw by the loop bounds)
                             if (origin_inside) stamp[(size_t)ty * c->tw + tx] = g;
                             else if (stamp[(size_t)ty * c->tw + tx] != g) mask |= 1u << ((ty - ty0) * 5 + (tx - tx0));
                         }
-                    b.cfl_zero = mask;
-                    b.hf_mul = c->h_hf_mul[(size_t)b.cy * c->bw + b.cx];
-                    P.sm[b.type].push_back(b);
                 }
+                b.cfl_zero = mask;
+                b.hf_mul = c->h_hf_mul[(size_t)b.cy * c->bw + b.cx];
+                out[cur[(size_t)g * NTY + b.type]++] = b;
             }
-        };
-        if (n_thr == 1) {
-            work(0);
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 1; t < n_thr; t++) th.emplace_back(work, t);
-            work(0);
-            for (auto& x : th) x.join();
-        }
-        for (const Part& P : parts) {  // the first failing group in group order
-            if (P.err == 1) return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock (%d,%d) type %u leaves the frame", P.bad.cy, P.bad.cx, P.bad.type);
-            if (P.err == 2) return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock spans too many tiles");
-        }
-        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
-            if (n_thr == 1) {
-                sm[t].swap(parts[0].sm[t]);
-                continue;
-            }
-            sm[t].reserve(t_count[t]);
-            for (const Part& P : parts) sm[t].insert(sm[t].end(), P.sm[t].begin(), P.sm[t].end());
-        }
     }
+    // the per-type lists as windows of h_blocks
+    struct BlockList {
+        const DevBlock* p = nullptr;
+        size_t n = 0;
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+        const DevBlock& operator[](size_t i) const { return p[i]; }
+        const DevBlock* begin() const { return p; }
+        const DevBlock* end() const { return p + n; }
+    };
+    BlockList sm[NTY];
+    for (int t = 0; t < NTY; t++) sm[t] = BlockList{c->h_blocks.data() + first_of_all[t], t_count[t]};
     mark("CfL masks + bins by type");
     // layout: [8x8-footprint types..., medium types..., large types...]; expensive items first so that the
     // tail of the single launch is made of cheap workgroups. Chroma-subsampled frames (c->sub) get one such layout per
     // channel: only the blocks aligned to the channel's grid, in the channel's own cell coordinates
     // (HFCoefficients.java:292-297, PassGroup.java:215-221), and one launch set per channel.
-    c->h_blocks.clear();
     std::vector<WorkItem> items;
     c->type_launches.clear();
     c->special_launches.clear();
@@ -405,11 +504,16 @@ jxl_status finalize_tables(jxl_ctx* c) {
     static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
     bool seg_overflow = false;
-    auto lay_out = [&](const std::vector<DevBlock>* lists, int channel) {
+    // preplaced: the lists ARE windows of h_blocks at these offsets (frames without chroma subsampling); else they are appended
+    auto lay_out = [&](const auto* lists, int channel, const uint32_t* preplaced) {
         std::vector<uint32_t> first_of(JXL_NUM_TRANSFORM_TYPES, 0);
         for (int pass = 0; pass < 2; pass++)
             for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) {
                 if (is_large(t) || lists[t].empty() || is_small(t) != (pass == 0)) continue;
+                if (preplaced) {
+                    first_of[t] = preplaced[t];
+                    continue;
+                }
                 first_of[t] = (uint32_t)c->h_blocks.size();
                 c->h_blocks.insert(c->h_blocks.end(), lists[t].begin(), lists[t].end());
             }
@@ -477,17 +581,21 @@ jxl_status finalize_tables(jxl_ctx* c) {
     };
     std::vector<int32_t> h_hfm_sub[3];
     if (!c->sub) {
-        lay_out(sm, -1);
+        lay_out(sm, -1, first_of_all);
     } else {
         for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
             if (is_large(t) && !sm[t].empty())
                 return fail(c, JXL_ERR_UNSUPPORTED, "128/256-edge varblocks in a chroma-subsampled frame");
+        // per channel: its own block lists in its own cell coordinates; h_blocks is rebuilt from them
+        std::vector<DevBlock> full[JXL_NUM_TRANSFORM_TYPES];
+        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++) full[t].assign(sm[t].begin(), sm[t].end());
+        c->h_blocks.clear();
         for (int ch = 0; ch < 3; ch++) {
             const int sy = c->sy[ch], sx = c->sx[ch], bwc = c->bw >> sx, bhc = c->bh >> sy;
             std::vector<DevBlock> sub_lists[JXL_NUM_TRANSFORM_TYPES];
             h_hfm_sub[ch].assign((size_t)bwc * bhc, 1);
             for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
-                for (const DevBlock& b : sm[t]) {
+                for (const DevBlock& b : full[t]) {
                     const int cy2 = b.cy >> sy, cx2 = b.cx >> sx;
                     if ((cy2 << sy) != b.cy || (cx2 << sx) != b.cx) continue;  // subsampled away
                     if (cy2 * 8 + JXL_TT[t].ph > (c->H >> sy) || cx2 * 8 + JXL_TT[t].pw > (c->W >> sx))
@@ -495,63 +603,47 @@ jxl_status finalize_tables(jxl_ctx* c) {
                     sub_lists[t].push_back(DevBlock{(uint16_t)cy2, (uint16_t)cx2, b.type, 0u, b.hf_mul});
                     h_hfm_sub[ch][(size_t)cy2 * bwc + cx2] = c->h_hf_mul[(size_t)b.cy * c->bw + b.cx];
                 }
-            lay_out(sub_lists, ch);
+            lay_out(sub_lists, ch, nullptr);
         }
     }
     if (seg_overflow) return fail(c, JXL_ERR_STATE, "more transform types in one launch class than an argument block holds");
     mark("launch layout");
-    c->large_first = (int)c->h_blocks.size();
-    for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
-        if (is_large(t)) c->h_blocks.insert(c->h_blocks.end(), sm[t].begin(), sm[t].end());
+    if (!c->sub) {  // the large types already sit behind the others (first_of_all)
+        size_t n_large = 0;
+        for (int t = 0; t < JXL_NUM_TRANSFORM_TYPES; t++)
+            if (is_large(t)) n_large += sm[t].size();
+        c->large_first = (int)(c->h_blocks.size() - n_large);
+    } else {
+        c->large_first = (int)c->h_blocks.size();  // (none: refused above)
+    }
     c->large_count = (int)c->h_blocks.size() - c->large_first;
     c->llf_first = c->large_first;  // only the 128/256-edge blocks take their LLF from the llf planes (k_llf)
     c->llf_count = c->large_count;
     for (int ch = 0; ch < 3 && c->sub; ch++) {
         if (!c->hfm_sub[ch].ensure(4 * std::max<size_t>(1, h_hfm_sub[ch].size()))) return fail(c, JXL_ERR_OOM, "device allocation failed");
-        HIP_TRY(c, hipMemcpyAsync(c->hfm_sub[ch].p, h_hfm_sub[ch].data(), 4 * h_hfm_sub[ch].size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpy(c->hfm_sub[ch].p, h_hfm_sub[ch].data(), 4 * h_hfm_sub[ch].size(), hipMemcpyHostToDevice));
     }
-
-    if (!c->blocks.ensure(sizeof(DevBlock) * std::max<size_t>(1, c->h_blocks.size())) ||
-        !c->items.ensure(sizeof(WorkItem) * std::max<size_t>(1, items.size())))
-        return fail(c, JXL_ERR_OOM, "device allocation failed (block tables)");
     const size_t nc = (size_t)c->bh * c->bw, nt = (size_t)c->th * c->tw;
-    mark("allocations");
-    if (!c->h_blocks.empty())
-        HIP_TRY(c, hipMemcpyAsync(c->blocks.p, c->h_blocks.data(), sizeof(DevBlock) * c->h_blocks.size(), hipMemcpyHostToDevice, c->stream));
+    // item lists of the persistent / wave kernels
+    std::vector<int> wg3_tab[2], wave_tab[2];
     {
         static const bool spatial = !(getenv("JXL_WG3_SPATIAL") && atoi(getenv("JXL_WG3_SPATIAL")) == 0);
-        std::vector<int> tab;
         for (int k = 0; k < 2; k++) {
             c->wg3_item_count[k] = 0;
             for (const auto& tl : c->type_launches) {
                 if (tl.cls != 2 + k || !spatial) continue;
-                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, tab, wg3_grid_cap(k == 1));
-                if (tab.empty()) continue;
-                if (!c->wg3_items[k].ensure(sizeof(int) * tab.size())) return fail(c, JXL_ERR_OOM, "device allocation failed (item list)");
-                HIP_TRY(c, hipMemcpy(c->wg3_items[k].p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
-                c->wg3_item_count[k] = (int)(tab.size() / 4);
+                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, wg3_tab[k], wg3_grid_cap(k == 1));
+                c->wg3_item_count[k] = (int)(wg3_tab[k].size() / 4);
             }
+            c->wave_item_count[k] = 0;
+            if (c->wave_segs.empty()) continue;
+            wave_item_table(c->h_blocks.data(), c->bw, c->wave_segs.data(), (int)c->wave_segs.size(), k, wave_tab[k]);
+            c->wave_item_count[k] = (int)(wave_tab[k].size() / 4);
         }
     }
-    for (int k = 0; k < 2; k++) {
-        c->wave_item_count[k] = 0;
-        if (c->wave_segs.empty()) continue;
-        std::vector<int> tab;
-        wave_item_table(c->h_blocks.data(), c->bw, c->wave_segs.data(), (int)c->wave_segs.size(), k, tab);
-        if (tab.empty()) continue;
-        if (!c->wave_items[k].ensure(sizeof(int) * tab.size())) return fail(c, JXL_ERR_OOM, "device allocation failed (item list)");
-        HIP_TRY(c, hipMemcpy(c->wave_items[k].p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
-        c->wave_item_count[k] = (int)(tab.size() / 4);
-    }
-    if (!items.empty())
-        HIP_TRY(c, hipMemcpyAsync(c->items.p, items.data(), sizeof(WorkItem) * items.size(), hipMemcpyHostToDevice, c->stream));
-    mark("block upload + item tables");
-    HIP_TRY(c, hipMemcpyAsync(c->hf_mul.p, c->h_hf_mul.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->sharp.p, c->h_sharp.data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    mark("item tables");
     // chroma-from-luma factor per 64x64 tile, HFCoefficients.java:177-181: base + factor / colorFactor in float (one IEEE
     // division and one addition, the same two operations the per-sample device code used to perform)
-    c->h_kx.resize(nt);
-    c->h_kb.resize(nt);
     {
         const volatile float cf = (float)c->p.color_factor;
         for (size_t i = 0; i < nt; i++) {
@@ -560,10 +652,51 @@ jxl_status finalize_tables(jxl_ctx* c) {
             c->h_kb[i] = c->p.base_corr_b + qb;
         }
     }
-    HIP_TRY(c, hipMemcpyAsync(c->xfy.p, c->h_kx.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->bfy.p, c->h_kb.data(), 4 * nt, hipMemcpyHostToDevice, c->stream));
-    for (int ch = 0; ch < 3; ch++)
-        HIP_TRY(c, hipMemcpyAsync(c->lf[ch].p, c->h_lf[ch].data(), 4 * nc, hipMemcpyHostToDevice, c->stream));
+    // the variable sections behind the fixed ones: block records, special-kernel items, item lists
+    size_t o = c->tab_fixed;
+    const size_t off_blocks = o, n_blk = sizeof(DevBlock) * c->h_blocks.size();
+    o = tab_up(o + std::max<size_t>(16, n_blk));
+    const size_t off_items = o, n_items = sizeof(WorkItem) * items.size();
+    o = tab_up(o + std::max<size_t>(16, n_items));
+    size_t off_wg3[2], off_wave[2];
+    for (int k = 0; k < 2; k++) {
+        off_wg3[k] = o;
+        o = tab_up(o + std::max<size_t>(16, sizeof(int) * wg3_tab[k].size()));
+        off_wave[k] = o;
+        o = tab_up(o + std::max<size_t>(16, sizeof(int) * wave_tab[k].size()));
+    }
+    const size_t total = o;
+    if (!tab_reserve(c, total, c->tab_fixed)) return fail(c, JXL_ERR_OOM, "host allocation failed (table staging)");
+    tab_bind_fixed(c, nc, nt);  // (the buffer may have moved)
+    if (n_blk) memcpy(c->h_tab + off_blocks, c->h_blocks.data(), n_blk);
+    if (n_items) memcpy(c->h_tab + off_items, items.data(), n_items);
+    for (int k = 0; k < 2; k++) {
+        if (!wg3_tab[k].empty()) memcpy(c->h_tab + off_wg3[k], wg3_tab[k].data(), sizeof(int) * wg3_tab[k].size());
+        if (!wave_tab[k].empty()) memcpy(c->h_tab + off_wave[k], wave_tab[k].data(), sizeof(int) * wave_tab[k].size());
+    }
+    if (total > c->tab.cap || !c->tab.p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // kernels of an earlier frame may still read the old arena
+        if (!c->tab.ensure(total + total / 4)) return fail(c, JXL_ERR_OOM, "device allocation failed (frame tables)");
+    }
+    mark("staging");
+    if (!c->tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->tab_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipMemcpyAsync(c->tab.p, c->h_tab, total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->tab_ev, c->stream));
+    c->tab_inflight = true;
+    {
+        char* d = static_cast<char*>(c->tab.p);
+        c->hf_mul.view(d + c->off_hfm, 4 * nc);
+        c->sharp.view(d + c->off_sharp, 4 * nc);
+        c->xfy.view(d + c->off_kx, 4 * nt);
+        c->bfy.view(d + c->off_kb, 4 * nt);
+        for (int i = 0; i < 3; i++) c->lf[i].view(d + c->off_lf[i], 4 * nc);
+        c->blocks.view(d + off_blocks, std::max<size_t>(16, n_blk));
+        c->items.view(d + off_items, std::max<size_t>(16, n_items));
+        for (int k = 0; k < 2; k++) {
+            c->wg3_items[k].view(d + off_wg3[k], sizeof(int) * wg3_tab[k].size());
+            c->wave_items[k].view(d + off_wave[k], sizeof(int) * wave_tab[k].size());
+        }
+    }
     // row f1: LF groups handed over as integers are dequantised + smoothed on the device, over the uploaded planes
     for (const auto& job : c->lf_jobs) {
         const jxl_lfquant_desc& d = job.d;
@@ -596,8 +729,10 @@ jxl_status finalize_tables(jxl_ctx* c) {
     // llf starts as a copy of lf (the LLF of an 8x8 block is its LF sample); k_llf overwrites the cells of larger blocks
     for (int ch = 0; ch < 3; ch++)
         HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be reused right after
-    mark("side tables + LF + sync");
+    // no synchronisation here: the staging buffer is only written again behind tab_wait(), the LF jobs have waited for their own
+    // sources, and everything that reads the tables is queued on this stream behind the transfer
+    if (!c->h_tab_pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    mark("transfer queued + LF");
     c->tables_dirty = false;
     static std::atomic<uint64_t> g_tables_gen{0};  // process-wide: a new context at a recycled address never matches an old key
     c->tables_gen = ++g_tables_gen;
@@ -1008,6 +1143,12 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     c->srgb8_tab.release();
     c->pq16_thr.release();
     c->srgb16_tab.release();
+    c->tab.release();
+    if (c->tab_ev) (void)hipEventDestroy(c->tab_ev);
+    if (c->h_tab) {
+        if (c->h_tab_pinned) (void)hipHostFree(c->h_tab);
+        else free(c->h_tab);
+    }
     for (int i = 0; i < 3; i++) { c->rp[i].release(); c->rp_tmp[i].release(); c->rp_noise[i].release(); }
     for (auto& b : c->mod_bufs) b.release();
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
@@ -1030,6 +1171,8 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     if (c->mod_join) (void)hipEventDestroy(c->mod_join);
     c->mod_ev = c->mod_join = nullptr;
     c->stage16.release();
+    if (c->map16_ev) (void)hipEventDestroy(c->map16_ev);
+    if (c->out_ev) (void)hipEventDestroy(c->out_ev);
     if (c->h_map16) (void)hipHostFree(c->h_map16);
     c->h_map16 = nullptr;
     c->wg3_items[0].release();
@@ -1092,20 +1235,16 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     bool ok = true;
     for (int i = 0; i < 3; i++) {
         ok = ok && c->coeff[i].ensure(4 * npx) && c->planeA[i].ensure(4 * npx) && c->planeB[i].ensure(4 * npx) &&
-             c->lf[i].ensure(4 * nc) && c->llf[i].ensure(4 * nc);
+             c->llf[i].ensure(4 * nc);  // (lf: a window of the table arena, finalize_tables)
         if (out_interleaved(p->out_format)) ok = ok && (i > 0 || c->outbuf[0].ensure(3 * (size_t)out_elem_size(p->out_format) * npx));
         else if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
     }
-    ok = ok && c->hf_mul.ensure(4 * nc) && c->sharp.ensure(4 * nc) && c->xfy.ensure(4 * nt) && c->bfy.ensure(4 * nt) &&
-         c->inv_sigma.ensure(4 * nc) && c->group_tmp.ensure(4 * 256 * 256);
+    ok = ok && c->inv_sigma.ensure(4 * nc) && c->group_tmp.ensure(4 * 256 * 256) && tab_begin_frame(c, nc, nt);
     if (!ok) return fail(c, JXL_ERR_OOM, "device allocation failed for a %dx%d frame", c->W, c->H);
     for (int i = 0; i < 3; i++) {
         HIP_TRY(c, hipMemsetAsync(c->coeff[i].p, 0, 4 * npx, c->stream));   // new int[sY][sX] (HFCoefficients.java:68)
         HIP_TRY(c, hipMemsetAsync(c->planeA[i].p, 0, 4 * npx, c->stream));  // frame buffer starts zeroed (ImageBuffer ctor)
-        c->h_lf[i].assign(nc, 0.0f);
     }
-    c->h_hf_mul.assign(nc, 1);
-    c->h_sharp.assign(nc, 0);
     c->h_sel.assign(nc, 255);
     c->h_xfy.assign(nt, 0);
     c->h_bfy.assign(nt, 0);
@@ -1345,15 +1484,19 @@ jxl_status jxl_vardct_put_group_i16(jxl_ctx* c, int32_t pass, int32_t group, con
     return JXL_OK;
 }
 
-jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* c, int16_t* planes[3], int32_t strides[3]) {
+jxl_status jxl_vardct_map_coeffs_i16_ex(jxl_ctx* c, int16_t* planes[3], int32_t strides[3], int32_t flags) {
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
     if (!planes || !strides) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null argument");
+    if (flags & ~JXL_MAP_NO_FILL) return fail(c, JXL_ERR_INVALID_ARGUMENT, "map: unknown flags");
     size_t off[4] = {0, 0, 0, 0};
     for (int ch = 0; ch < 3; ch++) off[ch + 1] = off[ch] + (((size_t)(c->W >> c->sx[ch]) * (c->H >> c->sy[ch]) * sizeof(int16_t) + 255) & ~(size_t)255);
+    // the buffer may be written again once the last commit's transfers have READ it (r4: an event, not the whole stream -- the
+    // previous frame's kernels and its output copy no longer hold the host back)
+    if (c->map16_inflight && c->map16_ev) HIP_TRY(c, hipEventSynchronize(c->map16_ev));
+    c->map16_inflight = false;
     if (c->h_map16_bytes < off[3]) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // an earlier commit may still be reading the old buffer
         if (c->h_map16) (void)hipHostFree(c->h_map16);
         c->h_map16 = nullptr;
         c->h_map16_bytes = 0;
@@ -1363,16 +1506,19 @@ jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* c, int16_t* planes[3], int32_t str
             return fail(c, JXL_ERR_OOM, "page-locked allocation of %zu bytes failed", off[3]);
         }
         c->h_map16_bytes = off[3];
-    } else {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    memset(c->h_map16, 0, off[3]);
+    if (!(flags & JXL_MAP_NO_FILL)) memset(c->h_map16, 0, off[3]);
+    c->map16_nofill = (flags & JXL_MAP_NO_FILL) != 0;
     for (int ch = 0; ch < 3; ch++) {
         planes[ch] = reinterpret_cast<int16_t*>(static_cast<char*>(c->h_map16) + off[ch]);
         strides[ch] = c->W >> c->sx[ch];
     }
     c->map16_valid = true;
     return JXL_OK;
+}
+
+jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* c, int16_t* planes[3], int32_t strides[3]) {
+    return jxl_vardct_map_coeffs_i16_ex(c, planes, strides, 0);
 }
 
 jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* c, int32_t rows[3]) {
@@ -1383,23 +1529,50 @@ jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* c, int32_t rows[3]) {
     return JXL_OK;
 }
 
-jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* c) {
+static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_groups) {
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open || !c->map16_valid) return fail(c, JXL_ERR_STATE, "map_coeffs_i16 first");
+    const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
+    if (written && n_groups != grs * gcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "commit: %d group flags for a frame of %d groups", n_groups, grs * gcs);
+    if (!written && c->map16_nofill) return fail(c, JXL_ERR_STATE, "planes mapped with JXL_MAP_NO_FILL: commit with the list of written groups");
     if (!c->stage16.ensure(c->h_map16_bytes)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
     size_t off = 0;
     for (int ch = 0; ch < 3; ch++) {
         const int Wc = c->W >> c->sx[ch], Hc = c->H >> c->sy[ch];
         const size_t bytes = (size_t)Wc * Hc * sizeof(int16_t);
+        if (written && c->map16_nofill) {
+            // groups the caller did not write read as zero (HFCoefficients.java:68: a fresh int[][]): zero-fill THEIR rectangles
+            // only -- a decoder writes every group of a frame, so this is normally nothing (the unconditional zero-fill of map
+            // was 50 MB of host stores per 4K frame, 1.0-1.4 ms)
+            int16_t* pl = reinterpret_cast<int16_t*>(static_cast<char*>(c->h_map16) + off);
+            const int gh = 256 >> c->sy[ch], gw = 256 >> c->sx[ch];
+            for (int g = 0; g < n_groups; g++) {
+                if (written[g]) continue;
+                const int y0 = (g / grs) * gh, x0 = (g % grs) * gw;
+                const int y1 = std::min(Hc, y0 + gh), x1 = std::min(Wc, x0 + gw);
+                for (int y = y0; y < y1; y++) memset(pl + (size_t)y * Wc + x0, 0, sizeof(int16_t) * (size_t)(x1 - x0));
+            }
+        }
         int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + off);
         HIP_TRY(c, hipMemcpyAsync(stg, static_cast<char*>(c->h_map16) + off, bytes, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(Wc, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), (int64_t)Wc, stg,
                            Wc, Hc, 0);
         off += (bytes + 255) & ~(size_t)255;
     }
+    if (!c->map16_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->map16_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->map16_ev, c->stream));
+    c->map16_inflight = true;
     c->coeff16_resident = !c->sub;
     return JXL_OK;
+}
+
+jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* c) { return commit_i16(c, nullptr, 0); }
+
+jxl_status jxl_vardct_commit_coeffs_i16_groups(jxl_ctx* c, const uint8_t* group_written, int32_t n_groups) {
+    if (!c) return JXL_ERR_INVALID_ARGUMENT;
+    if (!group_written) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null group flags");
+    return commit_i16(c, group_written, n_groups);
 }
 
 void* jxl_host_alloc(size_t bytes) {
@@ -1988,28 +2161,56 @@ jxl_status jxl_vardct_last_stage_ms(jxl_ctx* c, int32_t which, float* ms) {
 int32_t jxl_vardct_out_elem_size(const jxl_ctx* c) { return c ? c->result_elem : 0; }
 int32_t jxl_vardct_last_launch_count(const jxl_ctx* c) { return c ? c->last_launches : 0; }
 
-jxl_status jxl_vardct_read_output(jxl_ctx* c, void* const out[3], int64_t out_stride) {
-    jxl_status st = bind(c);
-    if (st) return st;
+// the copies of the last run's result planes to the host, queued on the context's stream
+static jxl_status enqueue_output(jxl_ctx* c, void* const out[3], int64_t out_stride) {
     if (!c->result[0]) return fail(c, JXL_ERR_STATE, "nothing has been run");
     if (!out || out_stride < c->W) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad output planes");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     const size_t es = (size_t)c->result_elem;
     // dense destination rows (the usual case): one linear copy per buffer -- hipMemcpy2D into pageable memory goes row by row
     // (measured: 31 ms for a 25 MB RGB8 4K frame against 3 ms linear)
     const bool dense = out_stride == c->W;
     if (c->result_interleaved) {  // one buffer, rows of 3*W samples; out_stride counts pixels
         if (!out[0]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output buffer");
-        if (dense) HIP_TRY(c, hipMemcpy(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost));
-        else HIP_TRY(c, hipMemcpy2D(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
-                                    hipMemcpyDeviceToHost));
+        if (dense) HIP_TRY(c, hipMemcpyAsync(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost, c->stream));
+        else HIP_TRY(c, hipMemcpy2DAsync(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
+                                         hipMemcpyDeviceToHost, c->stream));
         return JXL_OK;
     }
     for (int i = 0; i < 3; i++) {
         if (!out[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane %d", i);
-        if (dense) HIP_TRY(c, hipMemcpy(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost));
-        else HIP_TRY(c, hipMemcpy2D(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H, hipMemcpyDeviceToHost));
+        if (dense) HIP_TRY(c, hipMemcpyAsync(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost, c->stream));
+        else HIP_TRY(c, hipMemcpy2DAsync(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H,
+                                         hipMemcpyDeviceToHost, c->stream));
     }
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_read_output(jxl_ctx* c, void* const out[3], int64_t out_stride) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if ((st = enqueue_output(c, out, out_stride))) return st;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "device error: %s", hipGetErrorString(e));
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_read_output_begin(jxl_ctx* c, void* const out[3], int64_t out_stride) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if ((st = enqueue_output(c, out, out_stride))) return st;
+    if (!c->out_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->out_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->out_ev, c->stream));
+    c->out_inflight = true;
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_read_output_wait(jxl_ctx* c) {
+    jxl_status st = bind(c);
+    if (st) return st;
+    if (!c->out_inflight) return fail(c, JXL_ERR_STATE, "read_output_begin first");
+    HIP_TRY(c, hipEventSynchronize(c->out_ev));
+    c->out_inflight = false;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, JXL_ERR_DEVICE, "device error: %s", hipGetErrorString(e));
     return JXL_OK;

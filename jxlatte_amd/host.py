@@ -196,12 +196,16 @@ class Frame:
         self.ctx.call("jxl_vardct_put_group_i16", pass_, group, pp, strides)
         self._keep = getattr(self, "_keep", []) + [q]  # page-locked sources are read asynchronously: keep them alive until run()
 
-    def mapCoeffsI16(self):
+    def mapCoeffsI16(self, no_fill=False):
         """the frame's three coefficient planes as numpy views over the library's page-locked staging buffer
-        (jxl_vardct_map_coeffs_i16): write the groups in place, then commitCoeffsI16()"""
+        (jxl_vardct_map_coeffs_i16): write the groups in place, then commitCoeffsI16(). no_fill: the planes are not
+        zero-filled (jxl_vardct_map_coeffs_i16_ex, JXL_MAP_NO_FILL); commit then takes the list of written groups"""
         pp = (C.POINTER(C.c_int16) * 3)()
         strides = (C.c_int32 * 3)()
-        self.ctx.call("jxl_vardct_map_coeffs_i16", pp, strides)
+        if no_fill:
+            self.ctx.call("jxl_vardct_map_coeffs_i16_ex", pp, strides, 1)
+        else:
+            self.ctx.call("jxl_vardct_map_coeffs_i16", pp, strides)
         p = self.params
         out = []
         for c in range(3):
@@ -210,8 +214,14 @@ class Frame:
             out.append(np.frombuffer(buf, dtype=np.int16).reshape(h, w))
         return out
 
-    def commitCoeffsI16(self):
-        self.ctx.call("jxl_vardct_commit_coeffs_i16")
+    def commitCoeffsI16(self, written=None):
+        """written: one flag per group (Frame group order) -- the groups whose rectangles were fully written; the others read
+        as zero (jxl_vardct_commit_coeffs_i16_groups). None: everything in the mapped planes counts."""
+        if written is None:
+            self.ctx.call("jxl_vardct_commit_coeffs_i16")
+        else:
+            w = np.ascontiguousarray(written, np.uint8)
+            self.ctx.call("jxl_vardct_commit_coeffs_i16_groups", w.ctypes.data_as(C.POINTER(C.c_uint8)), int(w.size))
 
     def run(self):
         """enqueue all stages (asynchronous)"""
@@ -243,6 +253,24 @@ class Frame:
         else:
             pp = (C.c_void_p * 3)(*[out[c].ctypes.data for c in range(3)])
         self.ctx.call("jxl_vardct_read_output", pp, self.width)
+        return out
+
+    def readOutputBegin(self, out=None):
+        """queue the copy of the result to the host and return the destination array (jxl_vardct_read_output_begin); valid
+        after readOutputWait(). `out`: a (page-locked) array of the result's shape to copy into"""
+        if out is None:
+            out = self._out_array()
+        if self.params.out_format in (abi.OUT_RGB8, abi.OUT_RGB16) and (self.params.stages & abi.STAGE_OUT):
+            pp = (C.c_void_p * 3)(out.ctypes.data, None, None)
+        else:
+            pp = (C.c_void_p * 3)(*[out[c].ctypes.data for c in range(3)])
+        self.ctx.call("jxl_vardct_read_output_begin", pp, self.width)
+        self._pending_out = out
+        return out
+
+    def readOutputWait(self):
+        self.ctx.call("jxl_vardct_read_output_wait")
+        out, self._pending_out = self._pending_out, None
         return out
 
     def decodeFrame(self):

@@ -235,3 +235,56 @@ def test_mapped_int16_coefficient_planes(ctx, orc):
     with pytest.raises(_lib.JxlError):
         f2 = host.Frame(ctx, p, fr["weights"], fr["woffs"])
         f2.commitCoeffsI16()  # nothing mapped for this frame
+
+
+@pytest.mark.gpu
+def test_mapped_planes_without_zero_fill_and_split_read_output(ctx, orc):
+    """jxl_vardct_map_coeffs_i16_ex(JXL_MAP_NO_FILL) + commit_..._groups: the planes come back dirty, the groups the caller names
+    count, every other group reads as zero (the reference's fresh int[][], HFCoefficients.java:68); jxl_vardct_read_output_begin /
+    _wait return what read_output returns, with the next frame of the same context driven in between"""
+    fr = synth.make_vardct_frame(520, 520, seed=79, aligned=False)  # 3 x 3 groups
+    p = abi.VarDCTParams.from_buffer_copy(fr["params"])
+    p.stages = abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF
+    n_groups = synth.num_groups(fr)
+    assert n_groups == 9
+    written = np.ones(n_groups, np.uint8)
+    written[[2, 4]] = 0
+    # expected: the coefficients of the unwritten groups are zero
+    zeroed = dict(fr)
+    zeroed["coeff"] = fr["coeff"].copy()
+    for g in (2, 4):
+        gy, gx = divmod(g, 3)
+        zeroed["coeff"][:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256] = 0
+    exp = orc.vardct_frame(zeroed, stages=p.stages)
+    exp_full = orc.vardct_frame(fr, stages=p.stages)
+    f = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+    for g in fr["lfgroups"]:
+        f.setLFGroup(g)
+    # dirty the staging buffer first: a zero-filling map, garbage stores, no commit
+    planes = f.mapCoeffsI16()
+    for c in range(3):
+        planes[c][...] = 12345
+    planes = f.mapCoeffsI16(no_fill=True)
+    assert all(int(a.min()) == 12345 for a in planes)  # not zero-filled
+    for c in range(3):
+        planes[c][...] = fr["coeff"][c]  # every group written, two of them not named below
+    with pytest.raises(_lib.JxlError):
+        f.commitCoeffsI16()  # planes mapped without fill need the group list
+    with pytest.raises(_lib.JxlError):
+        f.commitCoeffsI16(written[:-1])  # wrong number of groups
+    f.commitCoeffsI16(written)
+    f.run()
+    got = f.readOutputBegin()
+    # the next frame of the same context while the copy is in flight: all groups written
+    f2 = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+    for g in fr["lfgroups"]:
+        f2.setLFGroup(g)
+    planes = f2.mapCoeffsI16(no_fill=True)
+    for c in range(3):
+        planes[c][...] = fr["coeff"][c]
+    f2.commitCoeffsI16(np.ones(n_groups, np.uint8))
+    f.readOutputWait()
+    assert_bits_equal(got, exp, "unwritten groups read as zero")
+    assert_bits_equal(f2.decodeFrame(), exp_full, "all groups written, no zero-fill")
+    with pytest.raises(_lib.JxlError):
+        f2.readOutputWait()  # nothing begun
