@@ -2988,8 +2988,12 @@ namespace {
 // stream -- a step is one launch on the critical path instead of two (1080p: 11 of 23 launches were verifications, 29 % of
 // the time). A mismatch is rare (the recurrence forgets its start within a few pairs, jxl_internal.h) and costs a second,
 // in-order run (mod_settle). RCT works in place on squeeze outputs the checks still read: it waits for them.
-jxl_status run_modular_plan(jxl_ctx* c, bool speculative) {
+// mode 0: every segmented step is checked (and repaired) by its own launch before the next one starts;
+// mode 1: the checks run on the side stream and only report (the r2 experiment);
+// mode 2 (r4, the default): the check of a step rides in the prologue of the NEXT step's walk launch and only reports.
+jxl_status run_modular_plan(jxl_ctx* c, int mode) {
     int launches = 0;
+    const bool speculative = mode == 1;
     hipStream_t s = c->stream, vs = speculative ? c->aux[0] : nullptr;
     bool checks_out = false;
     auto join = [&]() {
@@ -2998,7 +3002,17 @@ jxl_status run_modular_plan(jxl_ctx* c, bool speculative) {
         (void)hipStreamWaitEvent(s, c->mod_join, 0);
         checks_out = false;
     };
+    // mode 2: the last segmented step whose check has not been launched yet
+    SqueezeBatch pending{};
+    bool have_pending = false;
+    auto flush_pending = [&]() {  // nothing follows that could carry the check: a (tiny) report-only launch of its own
+        if (!have_pending) return;
+        launch_squeeze_verify(pending, s);
+        launches++;
+        have_pending = false;
+    };
     for (const ModOp& op : c->mod_ops) {
+        if (mode == 2 && op.kind != 4) flush_pending();
         switch (op.kind) {
         case 0: launch_inv_hsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, s); break;
         case 1: launch_inv_vsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, s); break;
@@ -3006,6 +3020,22 @@ jxl_status run_modular_plan(jxl_ctx* c, bool speculative) {
         case 3: (void)hipMemcpyAsync(op.o, op.a, 4 * (size_t)op.n, hipMemcpyDeviceToDevice, s); break;
         case 4: {
             SqueezeBatch bt = op.bt;
+            if (mode == 2) {
+                bt.flag = c->mod_flag.as<int32_t>();
+                if (have_pending) squeeze_fill_check(pending, bt);
+                have_pending = false;
+                launch_squeeze_walk(bt, s);
+                if (squeeze_can_fuse_check(bt)) {
+                    pending = bt;
+                    pending.n_chk = 0;
+                    have_pending = true;
+                } else {
+                    bt.flag = nullptr;  // (no compact tails: JXL_SQUEEZE_NO_TAIL) check and repair in place, as mode 0
+                    bt.n_chk = 0;
+                    launch_squeeze_verify(bt, s);
+                }
+                break;
+            }
             bt.flag = speculative ? c->mod_flag.as<int32_t>() : nullptr;
             launch_squeeze_batch(bt, s, vs, c->mod_ev);
             checks_out = checks_out || speculative;
@@ -3015,7 +3045,8 @@ jxl_status run_modular_plan(jxl_ctx* c, bool speculative) {
         }
         launches++;
     }
-    if (speculative) {
+    if (mode == 2) flush_pending();
+    if (mode != 0) {
         join();
         (void)hipMemcpyAsync(c->mod_flag_host, c->mod_flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, s);
         c->mod_pending = true;
@@ -3035,7 +3066,7 @@ jxl_status mod_settle(jxl_ctx* c) {
     *c->mod_flag_host = 0;
     HIP_TRY(c, hipMemset(c->mod_flag.p, 0, sizeof(int32_t)));
     c->mod_redos++;
-    const jxl_status st = run_modular_plan(c, false);
+    const jxl_status st = run_modular_plan(c, 0);
     if (st) return st;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return JXL_OK;
@@ -3047,12 +3078,15 @@ extern "C" {
 jxl_status jxl_modular_run(jxl_ctx* c) {
     jxl_status st = bind(c);
     if (st) return st;
-    // Built, measured, off by default: with the checks on the side stream a 1080p image takes 0.235 ms instead of 0.205 (the
-    // chain of dependent launches is what bounds it, ~9 us per launch, and the event pair per step costs more than the
-    // verification launch it removes from the main stream); 8K unchanged. JXL_SQUEEZE_SPECULATE=1 selects it (read per call).
+    // JXL_SQUEEZE_SPECULATE (read per call): unset / 2 = the check of every segmented step inside the next step's walk launch
+    // (r4: 13 launches per 1080p image instead of 23); 0 = a check-and-repair launch behind every step (the r1 form, and what a
+    // reported mismatch falls back to); 1 = the checks on the side stream (r2: measured slower, 0.235 against 0.205 ms -- the
+    // event pair per step costs more than the launch it moves away).
     const char* se = getenv("JXL_SQUEEZE_SPECULATE");
-    bool spec = se && atoi(se) != 0 && c->n_aux > 0;
-    if (spec && !c->mod_flag_host) {
+    int mode = se ? atoi(se) : 2;
+    if (mode < 0 || mode > 2) mode = 2;
+    if (mode == 1 && c->n_aux <= 0) mode = 0;
+    if (mode != 0 && !c->mod_flag_host) {
         if (!c->mod_flag.ensure(sizeof(int32_t))) return fail(c, JXL_ERR_OOM, "device allocation failed");
         HIP_TRY(c, hipMemset(c->mod_flag.p, 0, sizeof(int32_t)));
         HIP_TRY(c, hipHostMalloc((void**)&c->mod_flag_host, sizeof(int32_t), hipHostMallocDefault));
@@ -3060,7 +3094,7 @@ jxl_status jxl_modular_run(jxl_ctx* c) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->mod_ev, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->mod_join, hipEventDisableTiming));
     }
-    return run_modular_plan(c, spec);
+    return run_modular_plan(c, mode);
 }
 
 int32_t jxl_modular_redo_count(const jxl_ctx* c) { return c ? c->mod_redos : 0; }

@@ -261,13 +261,24 @@ __host__ __device__ inline int squeeze_warm(const SqueezeDesc& d);
 #endif
 constexpr int kSqueezeSeg = JXL_SQUEEZE_SEG;
 constexpr int kSqueezeWarm = JXL_SQUEEZE_WARM;
+// the segment-boundary arrays of an EARLIER step, checked in the prologue of a later step's walk kernel (r4)
+struct SqueezeCheck {
+    const int32_t* side;  // [nseg][n]
+    const int32_t* tail;  // [nseg - 1][n] (rows 0 .. nseg-2 used)
+    int n, nseg;
+};
 struct SqueezeBatch {
     int n;
     int horizontal;
     SqueezeDesc d[8];
     // k_squeeze_verify: nullptr = repair a mismatching row / column in place (the step is then exact before the next one
-    // starts); else = only report (atomicOr 1): the check runs beside the following steps and the host redoes the plan
+    // starts); else = only report (atomicOr 1): the check runs beside / behind the following steps and the host redoes the plan
     int32_t* flag;
+    // r4: the verification of the PREVIOUS segmented step rides in this step's walk launch -- every workgroup compares a slice
+    // of that step's compact side / tail arrays before it starts its own walk and reports a mismatch in `flag`; a 1080p plan is
+    // then 13 launches instead of 23 (the check launches were 6 us each on the chain of dependent launches that bounds it)
+    int n_chk;
+    SqueezeCheck chk[8];
 };
 // Small steps are bound by the time ONE wave needs for its segment (~130 cycles per pair), large ones by bandwidth: the host
 // gives steps of up to 8 Mi samples 32-pair segments with an 8-pair warm-up (measured: 1080p image 0.245 -> 0.195 ms) and
@@ -279,6 +290,12 @@ __host__ __device__ inline int squeeze_segments(const SqueezeDesc& d) {
 }
 // check_stream / ev: with bt.flag set, the verification launch goes to check_stream behind an event recorded on s
 void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t check_stream = nullptr, hipEvent_t ev = nullptr);
+// the two halves on their own: the walk (with the fused check of an earlier step, SqueezeBatch::chk) and the verification;
+// squeeze_can_fuse_check: the step is segmented and all its channels keep compact tail arrays
+void launch_squeeze_walk(const SqueezeBatch& bt, hipStream_t s);
+void launch_squeeze_verify(const SqueezeBatch& bt, hipStream_t s);
+bool squeeze_can_fuse_check(const SqueezeBatch& bt);
+void squeeze_fill_check(const SqueezeBatch& prev, SqueezeBatch& next);
 // a run of small steps in one launch: dev_steps = the steps' SqueezeBatch blocks in device memory, slot i of every step by
 // workgroup i (the caller has checked that slot i of a step depends on slot i of the step before only)
 void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slots, hipStream_t s);

@@ -123,8 +123,25 @@ __device__ __forceinline__ int32_t tend_fast_apply(int32_t a, const TendFast& t,
 // HZ = true: inverseHorizontalSqueeze walked the same way, lane = row, element (lane, k) at [lane * pitch + k]: a wave's
 // access touches 64 lines, but every lane then reads its own line to the end (L1 / L2 hits), no LDS transposition, no
 // workgroup barriers, nothing but registers -- the form k_inv_hsqueeze (LDS-staged) is compared against in DESIGN.md 4.3.
+// The fused check (SqueezeBatch::chk): this workgroup's share of an earlier step's segment boundaries. side[s][x] (the state
+// segment s started its own pairs from, after its warm-up) must equal tail[s - 1][x] (the last output of segment s - 1); both
+// arrays are compact [segment][lane], so boundary (s, x), s >= 1, is element i = (s - 1) * n + x of tail and n + i of side.
+__device__ __forceinline__ void squeeze_fused_check(const SqueezeBatch& bt) {
+    if (bt.n_chk <= 0) return;
+    const int64_t wg = blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+    const int64_t stride = (int64_t)gridDim.x * gridDim.y * gridDim.z * 64;
+    bool bad = false;
+    for (int q = 0; q < bt.n_chk; q++) {
+        const SqueezeCheck ck = bt.chk[q];
+        const int64_t total = (int64_t)(ck.nseg - 1) * ck.n;
+        for (int64_t i = wg * 64 + threadIdx.x; i < total; i += stride) bad = bad || ck.side[ck.n + i] != ck.tail[i];
+    }
+    if (__builtin_expect(__any(bad), 0) && threadIdx.x == 0) atomicOr(bt.flag, 1);
+}
+
 template <bool HZ>
 __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) {
+    squeeze_fused_check(bt);
     const SqueezeDesc d = bt.d[blockIdx.y];
     const int w = d.other, ah = d.adim, rh = d.rdim;  // w: number of lanes (columns for V, rows for H)
     // strides of the walked index k and of the lane index, per array
@@ -298,6 +315,7 @@ __global__ __launch_bounds__(64) void k_squeeze_verify(const SqueezeBatch bt) {
 // LDS write); each lane then walks its own row, four columns per step with the LDS reads hoisted ahead of the
 // serial chain; outputs overwrite the consumed inputs in LDS and leave as contiguous rows.
 __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
+    squeeze_fused_check(bt);
     const SqueezeDesc d = bt.d[blockIdx.y];
     const int aw = d.adim, rw = d.rdim, h = d.other;
     const int y0 = blockIdx.x * 64;
@@ -509,19 +527,28 @@ __global__ __launch_bounds__(256) void k_squeeze_chain(const SqueezeBatch* __res
     }
 }
 
+// (r4: the same chain with the channel's image kept in LDS from step to step -- residual plane in one coalesced sweep, walk from
+// LDS, image out in one sweep -- was built and measured: 0.1777 ms per 1080p image against 0.1784, and with the two following
+// steps of 60 / 67 pairs taken into the chain 0.1995. The chain is bound by the ~100 dependent instructions per pair that ONE wave
+// issues at ~6 cycles each, not by its memory round trips. Not kept.)
 void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slots, hipStream_t s) {
     if (n_steps <= 0 || n_slots <= 0) return;
     hipLaunchKernelGGL(k_squeeze_chain, dim3(n_slots), dim3(256), 0, s, dev_steps, n_steps);
 }
 
-void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t check_stream, hipEvent_t ev) {
-    if (bt.n <= 0) return;
-    int maxdim = 0, nseg = 1;
+static bool squeeze_grid(const SqueezeBatch& bt, int& maxdim, int& nseg) {
+    maxdim = 0;
+    nseg = 1;
     for (int i = 0; i < bt.n; i++) {
         maxdim = bt.d[i].other > maxdim ? bt.d[i].other : maxdim;
         nseg = squeeze_segments(bt.d[i]) > nseg ? squeeze_segments(bt.d[i]) : nseg;
     }
-    if (maxdim <= 0) return;
+    return bt.n > 0 && maxdim > 0;
+}
+
+void launch_squeeze_walk(const SqueezeBatch& bt, hipStream_t s) {
+    int maxdim, nseg;
+    if (!squeeze_grid(bt, maxdim, nseg)) return;
     const dim3 grid((maxdim + 63) / 64, bt.n, nseg);
     // H steps: the register walk (lane = row, strided access) while the step's planes stay cache-resident, the LDS-staged
     // kernel (coalesced rows) beyond that. JXL_HSQUEEZE_WALK_MAX overrides the threshold (output samples of the step).
@@ -533,6 +560,37 @@ void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t che
     if (bt.horizontal && h_lds) hipLaunchKernelGGL(k_inv_hsqueeze, grid, dim3(64), 0, s, bt);
     else if (bt.horizontal) hipLaunchKernelGGL(k_inv_squeeze_walk<true>, grid, dim3(64), 0, s, bt);
     else hipLaunchKernelGGL(k_inv_squeeze_walk<false>, grid, dim3(64), 0, s, bt);
+}
+
+void launch_squeeze_verify(const SqueezeBatch& bt, hipStream_t s) {
+    int maxdim, nseg;
+    if (!squeeze_grid(bt, maxdim, nseg) || nseg <= 1) return;
+    hipLaunchKernelGGL(k_squeeze_verify, dim3((maxdim + 63) / 64, bt.n), dim3(64), 0, s, bt);
+}
+
+bool squeeze_can_fuse_check(const SqueezeBatch& bt) {
+    bool any = false;
+    for (int i = 0; i < bt.n; i++) {
+        if (squeeze_segments(bt.d[i]) <= 1) continue;
+        if (!bt.d[i].tail || !bt.d[i].side) return false;
+        any = true;
+    }
+    return any;
+}
+
+void squeeze_fill_check(const SqueezeBatch& prev, SqueezeBatch& next) {
+    next.n_chk = 0;
+    for (int i = 0; i < prev.n; i++) {
+        const int nseg = squeeze_segments(prev.d[i]);
+        if (nseg <= 1) continue;
+        next.chk[next.n_chk++] = SqueezeCheck{prev.d[i].side, prev.d[i].tail, prev.d[i].other, nseg};
+    }
+}
+
+void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t check_stream, hipEvent_t ev) {
+    int maxdim, nseg;
+    if (!squeeze_grid(bt, maxdim, nseg)) return;
+    launch_squeeze_walk(bt, s);
     if (nseg > 1) {
         hipStream_t vs = s;
         if (bt.flag && check_stream && ev) {
@@ -540,7 +598,7 @@ void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t che
             (void)hipStreamWaitEvent(check_stream, ev, 0);
             vs = check_stream;
         }
-        hipLaunchKernelGGL(k_squeeze_verify, dim3((maxdim + 63) / 64, bt.n), dim3(64), 0, vs, bt);
+        launch_squeeze_verify(bt, vs);
     }
 }
 

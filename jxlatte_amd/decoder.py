@@ -567,6 +567,13 @@ class JXLDecoder:
     def getImageHeader(self):
         return self.info
 
+    def _trace(self, stage, planes, fused):
+        """test hook (tests/test_jvm_pin.py): `self.trace(frame_index, stage, planes, fused)` at the cut points where the pin-on-arrival
+        harness makes the reference dump its planes; None (the default): nothing"""
+        tr = getattr(self, "trace", None)
+        if tr is not None:
+            tr(self.frames_decoded - 1, stage, planes, fused)
+
     # -- frame-level pieces ---------------------------------------------------------------------------------------
     def _colors(self, fr):
         return 3 if (self.info.xyb_encoded or fr.encoding == VARDCT) else (1 if self.info.colour_space == CE_GRAY else 3)
@@ -723,6 +730,7 @@ class JXLDecoder:
         info, fe = self.info, self.fe
         n_mod = fr.num_modular_channels
         chans = [fe.modular_channel(i)[0] for i in range(n_mod)]
+        self._trace("mod", chans, False)  # ModularStream.getDecodedBuffer after applyTransforms (Frame.java:427-428)
         c_map = (1, 0, 2)
         for c in range(n_mod):
             is_mod_color = fr.encoding == MODULAR and c < colors
@@ -904,24 +912,34 @@ class JXLDecoder:
                     for c in range(3):
                         buffers[c] = planes[c]
             self._modular_buffers(fr, buffers, colors)
-            if fr.encoding == MODULAR and (fr.gab or fr.epf_iters > 0):
-                # Frame.performGabConvolution casts integer colour planes to float first (Frame.java:519:
-                # ImageBuffer.castToFloat = v * (1f / maxValue)); one-colour frames keep one plane (the backends feed the
-                # three-channel kernels three copies: Frame.java:642,661 read channel 0 in all three rounds)
+            # (trace: the cut points of integration/jvm_pin/StageDump.java. For a VarDCT frame the colour planes in `buffers` are
+            # already the fused kernel's result -- `fused` tells the listener to take the stages of planes 0..2 elsewhere)
+            fused = fr.encoding == VARDCT
+            self._trace("idct", buffers, fused)
+            self._trace("sub", buffers, fused)  # Frame.invertSubsampling: VarDCT colour planes only (inside the backend call)
+
+            def colour_planes_to_float():
+                # Frame.performGabConvolution / performEdgePreservingFilter cast integer colour planes to float first
+                # (Frame.java:519: ImageBuffer.castToFloat = v * (1f / maxValue)); one-colour frames keep one plane (the backends
+                # feed the three-channel kernels three copies: Frame.java:642,661 read channel 0 in all three rounds)
                 for c in range(colors):
                     if buffers[c].dtype != np.float32:
                         maxv = (1 << info.bits_per_sample) - 1
                         buffers[c] = be.modular_to_float(np.ascontiguousarray(buffers[c], np.int32), None, float(F(1) / F(maxv)))
-                planes = np.stack(buffers[:colors])
-                if fr.gab:
-                    planes = be.gab(planes, list(fr.gab1), list(fr.gab2))
-                if fr.epf_iters > 0:
-                    sigma = F(F(1) / F(fr.epf_sigma_modular))  # Frame.java:573-575
-                    planes = be.epf(planes, fr.epf_iters, None, float(sigma),
-                                    dict(channel_scale=list(fr.epf_channel_scale), pass0=fr.epf_pass0_sigma,
-                                         pass2=fr.epf_pass2_sigma, border_sad_mul=fr.epf_border_sad_mul))
+                return np.stack(buffers[:colors])
+            if fr.encoding == MODULAR and fr.gab:
+                planes = be.gab(colour_planes_to_float(), list(fr.gab1), list(fr.gab2))
                 for c in range(colors):
                     buffers[c] = np.ascontiguousarray(planes[c])
+            self._trace("gab", buffers, fused)
+            if fr.encoding == MODULAR and fr.epf_iters > 0:
+                sigma = F(F(1) / F(fr.epf_sigma_modular))  # Frame.java:573-575
+                planes = be.epf(colour_planes_to_float(), fr.epf_iters, None, float(sigma),
+                                dict(channel_scale=list(fr.epf_channel_scale), pass0=fr.epf_pass0_sigma,
+                                     pass2=fr.epf_pass2_sigma, border_sad_mul=fr.epf_border_sad_mul))
+                for c in range(colors):
+                    buffers[c] = np.ascontiguousarray(planes[c])
+            self._trace("epf", buffers, fused)
             if fr.lf_level > 0:  # JXLCodestreamDecoder.java:616-617: the frame's buffers as they stand after decodeFrame
                 self.lfBuffer[fr.lf_level - 1] = [np.array(b, copy=True) for b in buffers]
             # crop to the frame bounds: everything after the restoration filters works on header.bounds
@@ -971,6 +989,7 @@ class JXLDecoder:
                     planes = be.ycbcr(planes)
                 for c in range(3):
                     buffers[c] = np.ascontiguousarray(planes[c])
+            self._trace("xyb", buffers, False)  # JXLCodestreamDecoder.java:637: the frame's buffers after performColorTransforms
             if self.canvas[0] is None:
                 for c in range(len(self.canvas)):
                     self.canvas[c] = np.zeros((info.height, info.width), buffers[0].dtype)

@@ -191,17 +191,22 @@ def test_segmented_squeeze_adversarial(ctx, orc, horizontal, h_kernel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", None])
 @pytest.mark.parametrize("horizontal", [True, False])
-def test_plan_with_speculative_checks_redoes_adversarial_rows(ctx, orc, horizontal, monkeypatch):
-    """(JXL_SQUEEZE_SPECULATE=1, off by default) jxl_modular_run checks the segmented walks beside the following steps and only reports a mismatch; reading the result
-    then runs the plan again in order. Rows that never forget their start (see _adversarial) force that path: the output is
-    still the serial walk's, bit for bit, and the redo is counted. Ordinary data right after it: no redo."""
+def test_plan_with_speculative_checks_redoes_adversarial_rows(ctx, orc, horizontal, mode, monkeypatch):
+    """jxl_modular_run checks the segmented walks without holding the next step back -- inside the next step's walk launch
+    (the default, r4) or on a side stream (JXL_SQUEEZE_SPECULATE=1) -- and only reports a mismatch; reading the result then runs
+    the plan again in order. Rows that never forget their start (see _adversarial) force that path: the output is still the
+    serial walk's, bit for bit, and the redo is counted. Ordinary data right after it: no redo."""
     a, r = _adversarial(300, 70)
     exp = orc.inv_hsqueeze(a, r)
     if not horizontal:
         a, r, exp = a.T.copy(), r.T.copy(), exp.T.copy()
     sp = [(1 if horizontal else 0, 1, 0, 1)]
-    monkeypatch.setenv("JXL_SQUEEZE_SPECULATE", "1")
+    if mode is None:
+        monkeypatch.delenv("JXL_SQUEEZE_SPECULATE", raising=False)
+    else:
+        monkeypatch.setenv("JXL_SQUEEZE_SPECULATE", mode)
     before = ctx.lib.jxl_modular_redo_count(ctx.h)
     ms = host.ModularStream(ctx, [a, r], sp)
     out = ms.applyTransforms()
@@ -219,8 +224,10 @@ def test_plan_with_speculative_checks_redoes_adversarial_rows(ctx, orc, horizont
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("horizontal", [True, False])
-def test_plan_default_repairs_adversarial_rows_in_order(ctx, orc, horizontal):
-    """the default plan: the verification launch of a step repairs mismatching rows before the next step starts"""
+def test_plan_in_order_repairs_adversarial_rows(ctx, orc, horizontal, monkeypatch):
+    """JXL_SQUEEZE_SPECULATE=0 (the form a reported mismatch falls back to): the verification launch of a step repairs mismatching
+    rows before the next step starts -- no second run"""
+    monkeypatch.setenv("JXL_SQUEEZE_SPECULATE", "0")
     a, r = _adversarial(300, 70)
     exp = orc.inv_hsqueeze(a, r)
     if not horizontal:

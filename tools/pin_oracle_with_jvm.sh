@@ -4,12 +4,14 @@
 #   JXLATTE_SRC=/path/to/jxlatte  tools/pin_oracle_with_jvm.sh  [sample.jxl ...]
 #
 # 1. copies the reference's java/ tree to a scratch directory (the reference checkout is not touched);
-# 2. adds integration/jvm_pin/StageDump.java and inserts five one-line calls to it at the cut points of the hot path
-#    (anchored on the statements that call the stages, Frame.java:457-461 and JXLCodestreamDecoder.java:637);
-# 3. compiles everything with javac (no Meson needed), decodes every sample with JXLATTE_DUMP_PREFIX set, and also writes
-#    the reference's own PFM output (PFMWriter) per sample;
+# 2. tools/pin_patch_reference.sh adds integration/jvm_pin/StageDump.java and eight one-line calls to it at the cut points of the
+#    hot path: the modular stream after applyTransforms, the frame buffers after the modular -> buffer loop / invertSubsampling /
+#    Gaborish / EPF (Frame.java:427-461), after performColorTransforms (JXLCodestreamDecoder.java:637), and in the PNG writer
+#    after JXLImage.transform and after the integer cast (PNGWriter.java:65,105-111);
+# 3. compiles everything with javac (no Meson needed) and decodes every sample to PNG with JXLATTE_DUMP_PREFIX set;
 # 4. leaves the dumps under tests/golden/jvm/ -- `python -m pytest tests/test_jvm_pin.py` then compares the oracle with them
-#    bit for bit (the test skips while the directory is empty). Commit the dumps you want as fixtures: they are data.
+#    bit for bit, VarDCT and Modular frames and the PNG stage alike (the test skips while the directory is empty). Commit the
+#    dumps you want as fixtures: they are data.
 set -euo pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 : "${JXLATTE_SRC:?set JXLATTE_SRC to a checkout of Traneptora/jxlatte}"
@@ -17,24 +19,7 @@ command -v javac >/dev/null || { echo "pin_oracle_with_jvm: no javac on PATH (a 
 WORK=$(mktemp -d)
 trap 'rm -rf "$WORK"' EXIT
 cp -r "$JXLATTE_SRC/java" "$WORK/java"
-J=$WORK/java/com/traneptora/jxlatte
-cp "$ROOT/integration/jvm_pin/StageDump.java" "$J/util/StageDump.java"
-F=$J/frame/Frame.java
-D=$J/JXLCodestreamDecoder.java
-IMP='import com.traneptora.jxlatte.util.StageDump;'
-# Frame.decodeFrame: the four cut points, each anchored on the statement that starts the next stage
-sed -i "0,/^import /s//$IMP\nimport /" "$F"
-sed -i '/^        invertSubsampling();$/i\        StageDump.dump("idct", buffer);' "$F"
-sed -i '/^        if (header.restorationFilter.gab)$/i\        StageDump.dump("sub", buffer);' "$F"
-sed -i '/^        if (header.restorationFilter.epfIterations > 0)$/i\        StageDump.dump("gab", buffer);' "$F"
-sed -i '/^            performEdgePreservingFilter();$/a\        StageDump.dump("epf", buffer);' "$F"
-# JXLCodestreamDecoder.decode: after the colour transform of a frame
-sed -i "0,/^import /s//$IMP\nimport /" "$D"
-sed -i '/^            performColorTransforms(matrix, frame);$/a\            StageDump.dump("xyb", frame.getBuffer());' "$D"
-for pat in 'StageDump.dump("idct"' 'StageDump.dump("sub"' 'StageDump.dump("gab"' 'StageDump.dump("epf"'; do
-  grep -q "$pat" "$F" || { echo "pin_oracle_with_jvm: anchor for $pat not found in Frame.java (reference changed?)"; exit 3; }
-done
-grep -q 'StageDump.dump("xyb"' "$D" || { echo "pin_oracle_with_jvm: anchor not found in JXLCodestreamDecoder.java"; exit 3; }
+bash "$ROOT/tools/pin_patch_reference.sh" "$WORK/java"
 mkdir -p "$WORK/classes"
 find "$WORK/java" -name '*.java' ! -name 'ChebyschevApproximation.java' > "$WORK/sources.txt"   # (not in java/meson.build)
 javac --release 11 -d "$WORK/classes" @"$WORK/sources.txt"
@@ -47,7 +32,7 @@ java -version 2>&1 | head -1 > "$OUT/JVM_VERSION.txt"
 for s in "${SAMPLES[@]}"; do
   b=$(basename "$s" .jxl)
   echo "== $b"
-  JXLATTE_DUMP_PREFIX="$OUT/$b" java -cp "$WORK/classes" com.traneptora.jxlatte.JXLatte "$s" "$OUT/$b.pfm" || echo "   (reference failed on $b)"
+  JXLATTE_DUMP_PREFIX="$OUT/$b" java -cp "$WORK/classes" com.traneptora.jxlatte.JXLatte "$s" "$OUT/$b.png" || echo "   (reference failed on $b)"
 done
 ls "$OUT" | head -40
 echo "dumps under $OUT; now: python -m pytest tests/test_jvm_pin.py -q"
