@@ -5,6 +5,8 @@ import java.nio.ByteOrder;
 
 import com.traneptora.jxlatte.color.OpsinInverseMatrix;
 import com.traneptora.jxlatte.frame.Frame;
+import com.traneptora.jxlatte.color.ColorEncodingBundle;
+import com.traneptora.jxlatte.frame.FrameFlags;
 import com.traneptora.jxlatte.frame.FrameHeader;
 import com.traneptora.jxlatte.frame.LFGlobal;
 import com.traneptora.jxlatte.frame.features.RestorationFilter;
@@ -19,23 +21,42 @@ import com.traneptora.jxlatte.util.Point;
  * The hook tools/patch_reference_for_gpu.sh inserts into Frame.decodePassGroups (Frame.java:361-374): the loop
  * "passGroup.invertVarDCT(buffers, prev)" over passes and groups becomes ONE call of {@link #invertVarDCT}, which hands the
  * frame's quantised coefficients and side information to libjxlatte_amd.so through {@link NativeBackend} and fills the
- * frame's three float planes with the inverse transforms' output (stage mask JXL_STAGE_IDCT only: Gaborish, EPF and the colour
- * transform stay where the reference has them, so every later line of the reference runs unchanged on the same values).
+ * frame's three float planes with the result. Two forms, chosen with -Djxlatte.gpu=N (or JXLATTE_GPU=N in the environment):
  *
- * Enabled with -Djxlatte.gpu=1 (or JXLATTE_GPU=1 in the environment); otherwise the patched reference behaves as before.
+ *   1  the inverse transforms only (stage mask JXL_STAGE_IDCT): Gaborish, EPF and the colour transform stay where the reference
+ *      has them, so every later line of the reference runs unchanged on the same values; coefficients go group by group through
+ *      putGroup (int32, heap-backed staging). The smallest cut -- and the slowest form of the boundary.
+ *   2  the fused cut, the path bench.py measures: inverse transforms + Gaborish + EPF (+ the inverse XYB where nothing sits
+ *      between decodeFrame and performColorTransforms: no upsampling, patches, splines, noise, saveBeforeCT, LF level) in one
+ *      finishFrame; coefficients written in place into the library's page-locked int16 planes (mapCoeffsI16NoFill +
+ *      commitCoeffsI16Groups: three DMA transfers per frame; a group with a sample outside int16 falls back to putGroup). The
+ *      script guards the reference's own performGabConvolution / performEdgePreservingFilter (Frame.java:457-461) and invertXYB
+ *      (JXLCodestreamDecoder.java:266-267) with the flags this class sets on the frame (gpuRestored, gpuXYB).
+ *
+ * Otherwise the patched reference behaves as before.
  *
  * NOT COMPILED OR TESTED IN THIS REPOSITORY (no JDK in the build image). Our source, not reference code. Frames with chroma
- * subsampling are passed on to the reference's own path (the boundary supports them, this first hook does not map them).
+ * subsampling are passed on to the reference's own path (the boundary supports them, this hook does not map them).
  */
 public final class GpuFrameBridge {
     private GpuFrameBridge() {}
 
-    private static final boolean ENABLED =
-        "1".equals(System.getProperty("jxlatte.gpu")) || "1".equals(System.getenv("JXLATTE_GPU"));
+    private static final int MODE = mode();
     private static NativeBackend backend; // one context, reused for every frame of the process
 
+    private static int mode() {
+        String v = System.getProperty("jxlatte.gpu");
+        if (v == null)
+            v = System.getenv("JXLATTE_GPU");
+        if ("1".equals(v))
+            return 1;
+        if ("2".equals(v))
+            return 2;
+        return 0;
+    }
+
     public static boolean enabled(Frame frame) {
-        if (!ENABLED)
+        if (MODE == 0)
             return false;
         FrameHeader header = frame.getFrameHeader();
         for (int c = 0; c < 3; c++) {
@@ -43,6 +64,19 @@ public final class GpuFrameBridge {
                 return false;
         }
         return true;
+    }
+
+    /** mode 2: may the inverse XYB run inside the fused launch? Only if nothing sits between decodeFrame and performColorTransforms
+     *  (JXLCodestreamDecoder.java:615-637) and the frame's planes are not stored as an LF frame / reference before the transform. */
+    private static boolean fuseXYB(Frame frame) {
+        FrameHeader header = frame.getFrameHeader();
+        if (MODE != 2 || !frame.globalMetadata.isXYBEncoded())
+            return false;
+        if (header.upsampling != 1 || header.lfLevel != 0 || header.type == FrameFlags.LF_FRAME)
+            return false;
+        if ((header.flags & (FrameFlags.NOISE | FrameFlags.PATCHES | FrameFlags.SPLINES)) != 0)
+            return false;
+        return !(header.saveBeforeCT && !header.isLast);
     }
 
     private static ByteBuffer direct(int bytes) {
@@ -66,7 +100,7 @@ public final class GpuFrameBridge {
     }
 
     /** struct jxl_vardct_params (include/jxlatte_amd.h), field by field in declaration order: all members are 4 bytes wide. */
-    private static ByteBuffer packParams(Frame frame) {
+    private static ByteBuffer packParams(Frame frame, boolean xyb) {
         FrameHeader header = frame.getFrameHeader();
         LFGlobal lfGlobal = frame.getLFGlobal();
         RestorationFilter rf = header.restorationFilter;
@@ -74,7 +108,7 @@ public final class GpuFrameBridge {
         Dimension padded = frame.getPaddedFrameSize();
         ByteBuffer p = direct(4 * 64);
         p.putInt(padded.width).putInt(padded.height);
-        p.putInt(1); // stages = JXL_STAGE_IDCT
+        p.putInt(MODE == 2 ? (1 | 2 | 4 | (xyb ? 8 : 0)) : 1); // stages: JXL_STAGE_IDCT (| GAB | EPF | XYB: the fused cut)
         float globalScale = 65536.0f / lfGlobal.globalScale; // HFCoefficients.java:270-275
         p.putFloat(globalScale * (float)Math.pow(0.8D, header.xqmScale - 2D));
         p.putFloat(globalScale);
@@ -97,10 +131,19 @@ public final class GpuFrameBridge {
         for (int c = 0; c < 3; c++)
             p.putFloat(rf.epfChannelScale[c]);
         p.putFloat(rf.epfPass0SigmaScale).putFloat(rf.epfPass2SigmaScale).putFloat(rf.epfBorderSadMul);
-        p.putInt(0); // xyb: the colour transform stays in Java
-        for (int i = 0; i < 9 + 3 + 3; i++)
-            p.putFloat(0f); // opsin_matrix, opsin_bias, cbrt_opsin_bias: unused without JXL_STAGE_XYB
-        p.putFloat(255f); // intensity_target (unused)
+        p.putInt(xyb ? 1 : 0); // xyb: 0 = the colour transform stays in Java
+        // opsin_matrix (adapted to the image's primaries / white point as JXLCodestreamDecoder.java:592-595 does, not yet scaled
+        // by 255 / intensityTarget), opsin_bias, cbrt_opsin_bias: read only with JXL_STAGE_XYB. The three fields are private in
+        // the reference; tools/patch_reference_for_gpu.sh makes them public.
+        ColorEncodingBundle bundle = frame.globalMetadata.getColorEncoding();
+        OpsinInverseMatrix adapted = xyb ? matrix.getMatrix(bundle.prim, bundle.white) : matrix;
+        for (int i = 0; i < 9; i++)
+            p.putFloat(xyb ? adapted.matrix[i / 3][i % 3] : 0f);
+        for (int i = 0; i < 3; i++)
+            p.putFloat(xyb ? adapted.opsinBias[i] : 0f);
+        for (int i = 0; i < 3; i++)
+            p.putFloat(xyb ? adapted.cbrtOpsinBias[i] : 0f);
+        p.putFloat(xyb ? frame.globalMetadata.getToneMapping().intensityTarget : 255f); // intensity_target
         p.putInt(0).putInt(0); // transfer = JXL_TRANSFER_NONE, out_format = JXL_OUT_F32
         for (int i = 0; i < 6; i++)
             p.putInt(0); // jpeg_upsampling_y / x
@@ -129,12 +172,58 @@ public final class GpuFrameBridge {
         nb.setWeights(w, offs);
     }
 
+    /** mode 2: the groups written in place into the library's page-locked int16 planes (one pass; every sample of every group,
+     *  zeros included: the planes are not zero-filled). A group with a sample outside int16 is left out of the commit and sent
+     *  again as int32 (jxl_vardct_put_group overrides its rectangle). */
+    private static void putCoefficientsMapped(NativeBackend nb, Frame frame, PassGroup[] groups, int numGroups) {
+        ByteBuffer[] planes = nb.mapCoeffsI16NoFill();
+        Dimension padded = frame.getPaddedFrameSize();
+        java.nio.ShortBuffer[] sb = new java.nio.ShortBuffer[3];
+        for (int c = 0; c < 3; c++)
+            sb[c] = planes[c].order(ByteOrder.nativeOrder()).asShortBuffer();
+        byte[] written = new byte[numGroups];
+        short[] row = new short[256];
+        for (int group = 0; group < numGroups; group++) {
+            int[][][] q = groups[group].hfCoefficients.quantizedCoeffs;
+            Point loc = frame.getGroupLocation(group);
+            boolean fits = true;
+            for (int c = 0; c < 3 && fits; c++) {
+                int gh = q[c].length, gw = gh == 0 ? 0 : q[c][0].length;
+                for (int y = 0; y < gh && fits; y++) {
+                    int[] src = q[c][y];
+                    for (int x = 0; x < gw; x++) {
+                        int v = src[x];
+                        if (v < -32768 || v > 32767) {
+                            fits = false;
+                            break;
+                        }
+                        row[x] = (short)v;
+                    }
+                    if (fits) {
+                        sb[c].position(((loc.y << 8) + y) * padded.width + (loc.x << 8));
+                        sb[c].put(row, 0, gw);
+                    }
+                }
+            }
+            written[group] = (byte)(fits ? 1 : 0);
+        }
+        nb.commitCoeffsI16Groups(written);
+        for (int group = 0; group < numGroups; group++) {
+            if (written[group] != 0)
+                continue;
+            int[][][] q = groups[group].hfCoefficients.quantizedCoeffs;
+            int gh = q[0].length, gw = gh == 0 ? 0 : q[0][0].length;
+            nb.putGroup(0, group, ints(q[0], gh, gw), ints(q[1], gh, gw), ints(q[2], gh, gw), gw, gw, gw);
+        }
+    }
+
     public static synchronized void invertVarDCT(Frame frame, float[][][] buffers, PassGroup[][] passGroups, LFGroup[] lfGroups,
             int numPasses, int numGroups) {
         if (backend == null)
             backend = new NativeBackend(Integer.getInteger("jxlatte.gpu.device", 0));
         NativeBackend nb = backend;
-        nb.beginFrame(packParams(frame));
+        final boolean xyb = fuseXYB(frame);
+        nb.beginFrame(packParams(frame, xyb));
         setWeights(nb, frame.getHFGlobal().weights);
         for (LFGroup lfg : lfGroups) {
             HFMetadata m = lfg.hfMetadata;
@@ -157,13 +246,16 @@ public final class GpuFrameBridge {
                 ints(m.hfStreamBuffer[0], kh, kw), ints(m.hfStreamBuffer[1], kh, kw), blocks, m.blockList.length,
                 floats(lf[0], ch, cw), floats(lf[1], ch, cw), floats(lf[2], ch, cw));
         }
-        for (int pass = 0; pass < numPasses; pass++) {
-            for (int group = 0; group < numGroups; group++) {
-                int[][][] q = passGroups[pass][group].hfCoefficients.quantizedCoeffs;
-                int gh = q[0].length, gw = gh == 0 ? 0 : q[0][0].length;
-                // (the page-locked int16 form -- mapCoeffsI16 / commitCoeffsI16, INTEGRATION.md "The PCIe leg" -- is the fast
-                //  path; this first hook keeps the reference's int[3][][] groups as they are)
-                nb.putGroup(pass, group, ints(q[0], gh, gw), ints(q[1], gh, gw), ints(q[2], gh, gw), gw, gw, gw);
+        if (MODE == 2 && numPasses == 1) {
+            putCoefficientsMapped(nb, frame, passGroups[0], numGroups);
+        } else {
+            for (int pass = 0; pass < numPasses; pass++) {
+                for (int group = 0; group < numGroups; group++) {
+                    int[][][] q = passGroups[pass][group].hfCoefficients.quantizedCoeffs;
+                    int gh = q[0].length, gw = gh == 0 ? 0 : q[0][0].length;
+                    // (pass > 0 accumulates on the device, PassGroup.java:174-200)
+                    nb.putGroup(pass, group, ints(q[0], gh, gw), ints(q[1], gh, gw), ints(q[2], gh, gw), gw, gw, gw);
+                }
             }
         }
         Dimension padded = frame.getPaddedFrameSize();
@@ -179,5 +271,8 @@ public final class GpuFrameBridge {
                 fb.get(buffers[c][y], 0, Math.min(w, padded.width));
             }
         }
+        // what the reference must NOT do again for this frame (fields added by tools/patch_reference_for_gpu.sh)
+        frame.gpuRestored = MODE == 2;
+        frame.gpuXYB = xyb;
     }
 }

@@ -130,23 +130,43 @@ def test_java_bridge_packs_every_params_field():
     assert n * 4 == ctypes.sizeof(abi.VarDCTParams), (n, ctypes.sizeof(abi.VarDCTParams))
 
 
-def test_gpu_patch_script_anchors_match_the_reference():
-    """tools/patch_reference_for_gpu.sh: its two text patches land in the reference's Frame.java (skipped where the reference
-    checkout is absent, e.g. on the GPU box); the Java build itself needs a JDK and has never run here"""
+def test_gpu_patch_script_anchors_match_the_reference(tmp_path):
+    """tools/patch_reference_for_gpu.sh --patch-only: the call-site patch, the two Frame flags, the three guards (Gaborish, EPF,
+    invertXYB) and the three opsin fields land in the reference's sources, each exactly once (skipped where the reference checkout
+    is absent, e.g. on the GPU box); with the pin hooks applied first (PIN=1 order) as well. The Java build itself needs a JDK
+    and has never run here"""
     import shutil
     import subprocess
-    import tempfile
-    ref = "/root/reference/java/com/traneptora/jxlatte/frame/Frame.java"
-    if not os.path.exists(ref) or not shutil.which("perl"):
+    ref = "/root/reference/java"
+    if not os.path.isdir(ref) or not shutil.which("perl"):
         pytest.skip("reference checkout or perl absent")
-    script = open(os.path.join(ROOT, "tools", "patch_reference_for_gpu.sh")).read()
-    sed = re.search(r"^sed -i ('s/\^ +passGroup\.invertVarDCT.*') \"\$F\"$", script, re.M).group(1)
-    perl = re.search(r"^perl -0pi -e ('.*') \"\$F\"$", script, re.M).group(1)
-    with tempfile.TemporaryDirectory() as t:
-        f = os.path.join(t, "Frame.java")
-        shutil.copy(ref, f)
-        subprocess.run("sed -i %s %s && perl -0pi -e %s %s" % (sed, f, perl, f), shell=True, check=True)
-        out = open(f).read()
-    assert out.count("if (!gpuFrame) passGroup.invertVarDCT(buffers, prev);") == 1
-    assert out.count("GpuFrameBridge.invertVarDCT(this, buffers, passGroups, lfGroups, numPasses, numGroups);") == 1
-    assert out.index("GpuFrameBridge.enabled(this)") < out.index("if (!gpuFrame)")
+    for pin_first in (False, True):
+        j = tmp_path / ("java%d" % pin_first)
+        shutil.copytree(ref, str(j))
+        if pin_first:
+            r = subprocess.run(["bash", os.path.join(ROOT, "tools", "pin_patch_reference.sh"), str(j)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "patch_reference_for_gpu.sh"), "--patch-only", str(j)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        base = j / "com" / "traneptora" / "jxlatte"
+        out = (base / "frame" / "Frame.java").read_text()
+        assert out.count("if (!gpuFrame) passGroup.invertVarDCT(buffers, prev);") == 1
+        assert out.count("GpuFrameBridge.invertVarDCT(this, buffers, passGroups, lfGroups, numPasses, numGroups);") == 1
+        assert out.index("GpuFrameBridge.enabled(this)") < out.index("if (!gpuFrame)")
+        assert out.count("public boolean gpuRestored = false, gpuXYB = false;") == 1
+        assert out.count("if (header.restorationFilter.gab && !gpuRestored)\n            performGabConvolution();") == 1
+        assert out.count("if (header.restorationFilter.epfIterations > 0 && !gpuRestored)\n            performEdgePreservingFilter();") == 1
+        dec = (base / "JXLCodestreamDecoder.java").read_text()
+        assert dec.count("if (matrix != null && !frame.gpuXYB)\n            matrix.invertXYB(") == 1
+        ops = (base / "color" / "OpsinInverseMatrix.java").read_text()
+        for f in ("float[][] matrix;", "float[] opsinBias;", "float[] cbrtOpsinBias;"):
+            assert ops.count("    public final " + f) == 1 and ops.count("private final " + f) == 0
+        assert (base / "gpu" / "GpuFrameBridge.java").exists() and (base / "gpu" / "NativeBackend.java").exists()
+        # what the bridge names in the reference exists there (no JDK: checked as text)
+        bridge = (base / "gpu" / "GpuFrameBridge.java").read_text()
+        for name, where in (("getGroupLocation", out), ("getPaddedFrameSize", out), ("getLFGroupLocation", out), ("getHFGlobal", out),
+                            ("isXYBEncoded", (base / "bundle" / "ImageHeader.java").read_text()),
+                            ("getToneMapping", (base / "bundle" / "ImageHeader.java").read_text()),
+                            ("saveBeforeCT", (base / "frame" / "FrameHeader.java").read_text())):
+            decl = [l for l in where.splitlines() if name in l and "public" in l]
+            assert name in bridge and decl, name
