@@ -147,6 +147,14 @@ struct jxl_ctx {
     DevBuf tab;
     hipEvent_t tab_ev = nullptr;
     bool tab_inflight = false;
+    // r4: device work begin_frame used to queue for every frame, now done only where something depends on it (six memsets of
+    // 33 MB and three plane copies per 4K frame: 0.05 ms of device time, but nine runtime calls -- with a dozen contexts driving
+    // frames from a dozen threads the calls, not the bytes, were what the streaming rate paid for)
+    bool coeff_zero_pending = false;   // the coefficient planes have not been zeroed for this frame yet (put_group / run do it; a
+                                       // commit of the mapped planes overwrites every sample and needs none)
+    bool out_zero_pending = false;     // likewise the transform output planes: only needed when the varblocks do not tile the frame
+    bool blocks_cover = false;         // (finalize_tables) every 8x8 cell belongs to a varblock
+    bool llf_alias = false;            // no kernel writes the llf planes for this frame: they ARE the lf planes (no copy)
     size_t tab_fixed = 0, off_hfm = 0, off_sharp = 0, off_kx = 0, off_kb = 0, off_lf[3] = {0, 0, 0};
     HSpan<int32_t> h_hf_mul, h_sharp;
     std::vector<int32_t> h_xfy, h_bfy;
@@ -307,6 +315,19 @@ __global__ void k_widen2d(int32_t* dst, int64_t dpitch, const int16_t* src, int 
     *d = acc ? (int32_t)((uint32_t)*d + (uint32_t)v) : v;
 }
 
+// The same from page-locked HOST memory (r4: jxl_vardct_commit_coeffs_i16 without the staging copy): every lane moves 8 samples --
+// one 16-byte read over PCIe, two 16-byte stores -- so that the transfer is made of full-size read requests and needs no SDMA
+// transfer, no device staging buffer and no host API call per plane besides this launch. gw % 8 == 0.
+__global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ dst, int64_t dpitch, const int16_t* __restrict__ src, int gw, int gh) {
+    const int x8 = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x8 * 8 >= gw || y >= gh) return;
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const v4i_ pk = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(src + (int64_t)y * gw + x8 * 8));
+    int32_t* d = dst + (int64_t)y * dpitch + x8 * 8;
+    *reinterpret_cast<v4i_*>(d) = v4i_{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
+    *reinterpret_cast<v4i_*>(d + 4) = v4i_{(pk.z << 16) >> 16, pk.z >> 16, (pk.w << 16) >> 16, pk.w >> 16};
+}
+
 bool is_pinned_host(const void* p) {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
@@ -449,6 +470,13 @@ jxl_status finalize_tables(jxl_ctx* c) {
         }
     }
     c->h_blocks.resize(n_all);
+    {
+        // do the varblocks tile the frame? (they do in every valid stream: HFMetadata places a block on every cell; blocks cannot
+        // overlap -- the front-end's dctSelect grid has one owner per cell). Then the transforms write every output sample.
+        size_t cells = 0;
+        for (int t = 0; t < NTY; t++) cells += t_count[t] * (size_t)(JXL_TT[t].ph / 8) * (size_t)(JXL_TT[t].pw / 8);
+        c->blocks_cover = !c->sub && cells == (size_t)c->bh * c->bw;
+    }
     {
         std::vector<int32_t> stamp((size_t)c->th * c->tw, -1);
         DevBlock* out = c->h_blocks.data();
@@ -726,9 +754,13 @@ jxl_status finalize_tables(jxl_ctx* c) {
                           d.adaptive_smoothing, c->stream);
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // lfq_tmp is reused by the next job
     }
-    // llf starts as a copy of lf (the LLF of an 8x8 block is its LF sample); k_llf overwrites the cells of larger blocks
-    for (int ch = 0; ch < 3; ch++)
-        HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
+    // llf starts as a copy of lf (the LLF of an 8x8 block is its LF sample); k_llf overwrites the cells of the 128 / 256-edge
+    // blocks and (JXL_WG3_LLF_IN_ITEM=0) k_llf_wg3 those of every block above 8x8. With neither, nothing ever writes the llf
+    // planes: the kernels are handed the lf planes under both names and the three plane copies are not made (r4)
+    c->llf_alias = c->large_count == 0 && wg3_llf_in_item();
+    if (!c->llf_alias)
+        for (int ch = 0; ch < 3; ch++)
+            HIP_TRY(c, hipMemcpyAsync(c->llf[ch].p, c->lf[ch].p, 4 * nc, hipMemcpyDeviceToDevice, c->stream));
     // no synchronisation here: the staging buffer is only written again behind tab_wait(), the LF jobs have waited for their own
     // sources, and everything that reads the tables is queued on this stream behind the transfer
     if (!c->h_tab_pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -745,7 +777,7 @@ void fill_dev_frame(const jxl_ctx* c, DevFrame& f) {
     for (int ch = 0; ch < 3; ch++) {
         f.coeff[ch] = c->coeff[ch].as<int32_t>();
         f.lf[ch] = c->lf[ch].as<float>();
-        f.llf[ch] = c->llf[ch].as<float>();
+        f.llf[ch] = c->llf_alias ? c->lf[ch].as<float>() : c->llf[ch].as<float>();
         f.scale_factor[ch] = c->p.scale_factor[ch];
         f.quant_bias[ch] = c->p.quant_bias[ch];
     }
@@ -1241,10 +1273,8 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     }
     ok = ok && c->inv_sigma.ensure(4 * nc) && c->group_tmp.ensure(4 * 256 * 256) && tab_begin_frame(c, nc, nt);
     if (!ok) return fail(c, JXL_ERR_OOM, "device allocation failed for a %dx%d frame", c->W, c->H);
-    for (int i = 0; i < 3; i++) {
-        HIP_TRY(c, hipMemsetAsync(c->coeff[i].p, 0, 4 * npx, c->stream));   // new int[sY][sX] (HFCoefficients.java:68)
-        HIP_TRY(c, hipMemsetAsync(c->planeA[i].p, 0, 4 * npx, c->stream));  // frame buffer starts zeroed (ImageBuffer ctor)
-    }
+    c->coeff_zero_pending = true;  // new int[sY][sX] (HFCoefficients.java:68): zeroed when a group is put / the frame runs
+    c->out_zero_pending = true;    // frame buffer starts zeroed (ImageBuffer ctor): zeroed at run time if a cell has no varblock
     c->h_sel.assign(nc, 255);
     c->h_xfy.assign(nt, 0);
     c->h_bfy.assign(nt, 0);
@@ -1429,6 +1459,30 @@ jxl_status jxl_stage_lf_dequant(jxl_ctx* c, const jxl_lfquant_desc* d, float bas
     return JXL_OK;
 }
 
+// the deferred zero-fills of begin_frame
+static jxl_status zero_coeff_planes(jxl_ctx* c) {
+    if (!c->coeff_zero_pending) return JXL_OK;
+    const size_t npx = (size_t)c->W * c->H;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemsetAsync(c->coeff[i].p, 0, 4 * npx, c->stream));
+    c->coeff_zero_pending = false;
+    return JXL_OK;
+}
+static jxl_status zero_output_planes(jxl_ctx* c) {
+    if (!c->out_zero_pending) return JXL_OK;
+    const size_t npx = (size_t)c->W * c->H;
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemsetAsync(c->planeA[i].p, 0, 4 * npx, c->stream));
+    c->out_zero_pending = false;
+    return JXL_OK;
+}
+
+// before the transforms of a frame run (finalize_tables has run): whatever of begin_frame's zero-fills is still owed
+static jxl_status pre_run_zero(jxl_ctx* c) {
+    jxl_status st = zero_coeff_planes(c);
+    if (st) return st;
+    if (c->out_zero_pending && c->blocks_cover && (c->p.stages & JXL_STAGE_IDCT)) c->out_zero_pending = false;  // every sample is written
+    return zero_output_planes(c);
+}
+
 jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const int32_t* const q[3], const int32_t stride[3]) {
     jxl_status st = bind(c);
     if (st) return st;
@@ -1436,6 +1490,7 @@ jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const i
     c->coeff16_resident = false;
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
+    if ((st = zero_coeff_planes(c))) return st;
     const int gy = group / grs, gx = group % grs;  // Frame.getGroupLocation (Frame.java:883)
     const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);  // getGroupSize (:905)
     for (int ch = 0; ch < 3; ch++) {
@@ -1464,6 +1519,7 @@ jxl_status jxl_vardct_put_group_i16(jxl_ctx* c, int32_t pass, int32_t group, con
     c->coeff16_resident = false;
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
+    if ((st = zero_coeff_planes(c))) return st;
     const int gy = group / grs, gx = group % grs;
     const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);
     // staging: one 256 x 256 int16 tile per (group, channel) in a ring large enough for a frame, so that the copies of a
@@ -1536,7 +1592,6 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (written && n_groups != grs * gcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "commit: %d group flags for a frame of %d groups", n_groups, grs * gcs);
     if (!written && c->map16_nofill) return fail(c, JXL_ERR_STATE, "planes mapped with JXL_MAP_NO_FILL: commit with the list of written groups");
-    if (!c->stage16.ensure(c->h_map16_bytes)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
     size_t off = 0;
     for (int ch = 0; ch < 3; ch++) {
         const int Wc = c->W >> c->sx[ch], Hc = c->H >> c->sy[ch];
@@ -1554,16 +1609,32 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
                 for (int y = y0; y < y1; y++) memset(pl + (size_t)y * Wc + x0, 0, sizeof(int16_t) * (size_t)(x1 - x0));
             }
         }
+        // r4: the widening kernel reads the page-locked planes over PCIe itself -- no SDMA transfer, no device staging copy, one
+        // runtime call per plane instead of two. With a dozen contexts committing from a dozen threads the hipMemcpyAsync calls
+        // had become the slowest part of a frame (commit 2-3 ms per frame and thread against 0.06; tools/r4_zerocopy_ab.sh).
+        // JXL_COMMIT_ZEROCOPY=0: the staged form (and what JXL_WG3_I16 needs: the int16 planes resident on the device)
+        static const bool zero_copy = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
+        void* hdev = nullptr;
+        if (zero_copy && (Wc & 7) == 0 && hipHostGetDevicePointer(&hdev, c->h_map16, 0) == hipSuccess && hdev) {
+            hipLaunchKernelGGL(k_widen2d_host8, dim3(ceil_div(Wc / 8, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(),
+                               (int64_t)Wc, reinterpret_cast<const int16_t*>(static_cast<char*>(hdev) + off), Wc, Hc);
+            off += (bytes + 255) & ~(size_t)255;
+            continue;
+        }
+        (void)hipGetLastError();
+        if (!c->stage16.ensure(c->h_map16_bytes)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
         int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + off);
         HIP_TRY(c, hipMemcpyAsync(stg, static_cast<char*>(c->h_map16) + off, bytes, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(Wc, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), (int64_t)Wc, stg,
                            Wc, Hc, 0);
         off += (bytes + 255) & ~(size_t)255;
     }
+    c->coeff_zero_pending = false;  // every sample of the three planes has just been written
     if (!c->map16_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->map16_ev, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->map16_ev, c->stream));
     c->map16_inflight = true;
-    c->coeff16_resident = !c->sub;
+    static const bool zc = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
+    c->coeff16_resident = !c->sub && !zc;  // (the device staging copy of the int16 planes: not made by the zero-copy form)
     return JXL_OK;
 }
 
@@ -1606,6 +1677,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
     st = finalize_tables(c);
     if (st) return st;
+    if ((st = pre_run_zero(c))) return st;
     const jxl_vardct_params& p = c->p;
     hipStream_t s = c->stream;
     int launches = 0;
@@ -1961,6 +2033,7 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
         if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
         st = finalize_tables(c);
         if (st) return st;
+        if ((st = pre_run_zero(c))) return st;  // (on the frame's own stream: the shared launches are ordered behind it below)
         ok = batchable(c);
     }
     if (!ok) {

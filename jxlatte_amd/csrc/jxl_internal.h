@@ -122,6 +122,7 @@ void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment
 int wg3_grid_cap(bool big);  // workgroups of a single-frame launch (JXL_WG3_GRID / JXL_WG3_GRID_BIG)
 bool wg3_handles(int type);
 bool wg3_big(int type);  // the 64-point family: its own launch (register / LDS class)
+bool wg3_llf_in_item();  // finalizeLLF inside the k_idct_wg3 items (default) or as a launch of its own writing the llf planes
 int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],
                    Wg3Args& a);
 void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s);

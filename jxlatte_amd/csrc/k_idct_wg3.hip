@@ -813,6 +813,11 @@ extern "C" int jxl_debug_set_stamps3(void* dev_ptr) {
 }
 #endif
 
+bool wg3_llf_in_item() {
+    static const bool v = !(getenv("JXL_WG3_LLF_IN_ITEM") && atoi(getenv("JXL_WG3_LLF_IN_ITEM")) == 0);
+    return v;
+}
+
 bool wg3_handles(int type) {
     // experiment knob: JXL_WG3_SKIP=<bit mask of types> leaves those types to the per-channel kernels of k_idct.hip
     static const unsigned skip = getenv("JXL_WG3_SKIP") ? (unsigned)strtoul(getenv("JXL_WG3_SKIP"), nullptr, 0) : 0u;
@@ -856,8 +861,7 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.total_items = 0;
     a.img_floats = 0;
     a.items = nullptr;
-    static const bool llf_in_item = !(getenv("JXL_WG3_LLF_IN_ITEM") && atoi(getenv("JXL_WG3_LLF_IN_ITEM")) == 0);
-    a.llf_in_item = llf_in_item ? 1 : 0;
+    a.llf_in_item = wg3_llf_in_item() ? 1 : 0;
     a.coeff16[0] = a.coeff16[1] = a.coeff16[2] = nullptr;
     static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
     for (int i = 0; i < n_seg; i++) {

@@ -236,7 +236,9 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
         for (int t = 0; t < NT; t++) {
             const float d = dist[i][t] * bmul[i];
             const float v = 1.0f - d * ep.sigma_scale * s;
-            const float w = v < 0.0f ? 0.0f : v;
+            // max(v, 0): the reference's `v < 0 ? 0 : v` (Frame.java:676-678) for every v that is not NaN or -0. v = 1 - x is -0 for no x,
+            // and NaN only where inv sigma is not finite or the samples are not -- pixels the `skip` select below replaces anyway
+            const float w = __builtin_fmaxf(v, 0.0f);
             dist[i][t] = w;
             sw = sw + w;
         }
@@ -288,20 +290,29 @@ __device__ __forceinline__ void patch_sigma(int ry, int rx, const TileCtx& tc, c
                                             const EpfParams& ep, float s_inv[4 * PH], float bmul[4 * PH]) {
     const int gx0 = tc.ix0 + rx;
     // a 4-pixel run touches at most two cells: look up the first and the last, pick per pixel. Out-of-frame
-    // positions (only on edge tiles) get some in-range cell; they are recomputed by the mirror fix-up.
-    const int cxa = (min(max(gx0, 0), tc.W - 1) >> 3) - scx0, cxb = (min(max(gx0 + 3, 0), tc.W - 1) >> 3) - scx0;
+    // positions (only on edge tiles: a uniform branch) get some in-range cell; they are recomputed by the mirror fix-up.
+    int cxa = (gx0 >> 3) - scx0, cxb = ((gx0 + 3) >> 3) - scx0;
+    if (tc.edge) {
+        cxa = (min(max(gx0, 0), tc.W - 1) >> 3) - scx0;
+        cxb = (min(max(gx0 + 3, 0), tc.W - 1) >> 3) - scx0;
+    }
+    // pixel i of the run lies in the first cell while i < 8 - (gx0 & 7); it is on an 8x8-border column when (gx0 + i) & 7 is 0 or 7:
+    // bit i of 0x8181 >> (gx0 & 7)
+    const int first_n = 8 - (gx0 & 7);
+    const uint32_t colb = 0x8181u >> (gx0 & 7);
 #pragma unroll
     for (int py = 0; py < PH; py++) {
         const int gy = tc.iy0 + ry + py;
         const bool rowb = ((gy + 1) & 7) < 2;  // gy & 7 is 7 or 0
-        const int crow = ((min(max(gy, 0), tc.H - 1) >> 3) - scy0) * 16;
+        int crow = ((gy >> 3) - scy0) * 16;
+        if (tc.edge) crow = ((min(max(gy, 0), tc.H - 1) >> 3) - scy0) * 16;
         const float sa = sig[crow + cxa], sb = sig[crow + cxb];
+        const uint32_t bm = rowb ? 0xfu : colb;
 #pragma unroll
         for (int px = 0; px < 4; px++) {
-            const int gx = gx0 + px;
             // epfWeight's border factor (:672-675): border_sad_mul on 8x8-border rows/columns, else 1 (d * 1 == d)
-            bmul[py * 4 + px] = (rowb || ((gx + 1) & 7) < 2) ? ep.border_sad_mul : 1.0f;
-            s_inv[py * 4 + px] = (gx >> 3) == (gx0 >> 3) ? sa : sb;
+            bmul[py * 4 + px] = (bm & (1u << px)) ? ep.border_sad_mul : 1.0f;
+            s_inv[py * 4 + px] = px < first_n ? sa : sb;
         }
     }
 }

@@ -78,5 +78,6 @@ def test_int16_resident_coefficients_are_bit_exact():
     planes instead of the widened int32 planes; same bits as the oracle"""
     env = dict(os.environ)
     env["JXL_WG3_I16"] = "1"
+    env["JXL_COMMIT_ZEROCOPY"] = "0"  # the experiment reads the staged int16 planes on the device
     r = subprocess.run([sys.executable, "-c", SCRIPT_I16], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RESULT 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

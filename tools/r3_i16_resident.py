@@ -3,6 +3,7 @@
 alone on the device: stage time by the library's events, output compared with the int32 run of the same process order.
    python tools/r3_i16_resident.py            (run once with JXL_WG3_I16=1 and once without; the env is read once per process)"""
 import ctypes as C, os, sys, time, hashlib
+os.environ.setdefault("JXL_COMMIT_ZEROCOPY", "0")  # the experiment reads the staged int16 planes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from jxlatte_amd import _lib, host, synth
