@@ -37,6 +37,54 @@ static void rethrow(JNIEnv* e, jxl_ctx* c, jxl_status st) {
     } while (0)
 #define ADDR(buf) ((buf) ? (*e)->GetDirectBufferAddress(e, (buf)) : NULL)
 
+/* Argument checks (r4): the library trusts the sizes its C callers state; a Java caller states them twice -- as integers and as
+ * the capacity of the direct buffers it passes -- and the shim makes the two agree before anything is read or written. */
+static void bad_arg(JNIEnv* e, const char* what) {
+    if (!(*e)->ExceptionCheck(e)) (*e)->ThrowNew(e, (*e)->FindClass(e, "java/lang/IllegalArgumentException"), what);
+}
+/* a direct buffer of at least `bytes` bytes */
+static int has_room(JNIEnv* e, jobject buf, jlong bytes) {
+    return buf && bytes >= 0 && (*e)->GetDirectBufferAddress(e, buf) && (*e)->GetDirectBufferCapacity(e, buf) >= bytes;
+}
+#define NEED(buf, bytes)                                                        \
+    do {                                                                        \
+        if (!has_room(e, (buf), (jlong)(bytes))) {                              \
+            bad_arg(e, "jxlatte_amd: direct buffer " #buf " missing or too small"); \
+            return;                                                             \
+        }                                                                       \
+    } while (0)
+/* an optional buffer: null, or large enough */
+#define NEED_OPT(buf, bytes)          \
+    do {                              \
+        if (buf) NEED(buf, bytes);    \
+    } while (0)
+static jlong area(jlong h, jlong w) { return h < 0 || w < 0 ? -1 : h * w; }
+/* n floats / ints of a Java array into dst; 0 (exception pending) if the array is null or shorter */
+static int get_floats(JNIEnv* e, jfloatArray a, jsize n, float* dst) {
+    if (!a || (*e)->GetArrayLength(e, a) < n) {
+        bad_arg(e, "jxlatte_amd: float array missing or too short");
+        return 0;
+    }
+    (*e)->GetFloatArrayRegion(e, a, 0, n, dst);
+    return !(*e)->ExceptionCheck(e);
+}
+static int get_ints(JNIEnv* e, jintArray a, jsize n, jint* dst) {
+    if (!a || (*e)->GetArrayLength(e, a) < n) {
+        bad_arg(e, "jxlatte_amd: int array missing or too short");
+        return 0;
+    }
+    (*e)->GetIntArrayRegion(e, a, 0, n, dst);
+    return !(*e)->ExceptionCheck(e);
+}
+#define GETF(arr, n, dst)                              \
+    do {                                               \
+        if (!get_floats(e, (arr), (n), (dst))) return; \
+    } while (0)
+#define GETI(arr, n, dst)                            \
+    do {                                             \
+        if (!get_ints(e, (arr), (n), (dst))) return; \
+    } while (0)
+
 JNIEXPORT jlong JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_create(JNIEnv* e, jclass k, jint device) {
     (void)k;
     jxl_ctx* c = NULL;
@@ -67,7 +115,8 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_beginFrame(
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_setWeights(JNIEnv* e, jobject self, jobject weights, jintArray offs) {
     jxl_ctx* c = ctx_of(e, self);
     jint o[51];
-    (*e)->GetIntArrayRegion(e, offs, 0, 51, o);
+    GETI(offs, 51, o);
+    NEED(weights, 4);
     CHECK(jxl_vardct_set_weights(c, (const float*)ADDR(weights), (size_t)(*e)->GetDirectBufferCapacity(e, weights) / 4, (const int32_t*)o));
 }
 
@@ -307,18 +356,24 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularAppl
     jxl_channel ci[256], co[256];
     jxl_squeeze_param sp[64];
     jint w[256], h[256], ow[256], oh[256], spv[256];
-    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
-    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
-    (*e)->GetIntArrayRegion(e, outWidths, 0, n_out, ow);
-    (*e)->GetIntArrayRegion(e, outHeights, 0, n_out, oh);
-    (*e)->GetIntArrayRegion(e, squeezeParams, 0, n_sp * 4, spv);
+    GETI(widths, n, w);
+    GETI(heights, n, h);
+    GETI(outWidths, n_out, ow);
+    GETI(outHeights, n_out, oh);
+    GETI(squeezeParams, n_sp * 4, spv);
     for (jsize i = 0; i < n; i++) {
+        jobject b = (*e)->GetObjectArrayElement(e, chans, i);
+        if ((*e)->ExceptionCheck(e)) return;
         ci[i].width = w[i]; ci[i].height = h[i];
-        ci[i].data = (int32_t*)ADDR((*e)->GetObjectArrayElement(e, chans, i));
+        if (area(h[i], w[i]) > 0) NEED(b, 4 * area(h[i], w[i]));
+        ci[i].data = (int32_t*)ADDR(b);
     }
     for (jsize i = 0; i < n_out; i++) {
+        jobject b = (*e)->GetObjectArrayElement(e, out, i);
+        if ((*e)->ExceptionCheck(e)) return;
         co[i].width = ow[i]; co[i].height = oh[i];
-        co[i].data = (int32_t*)ADDR((*e)->GetObjectArrayElement(e, out, i));
+        if (area(oh[i], ow[i]) > 0) NEED(b, 4 * area(oh[i], ow[i]));
+        co[i].data = (int32_t*)ADDR(b);
     }
     for (jsize i = 0; i < n_sp; i++) {
         sp[i].horizontal = spv[4 * i]; sp[i].in_place = spv[4 * i + 1]; sp[i].begin_c = spv[4 * i + 2]; sp[i].num_c = spv[4 * i + 3];
@@ -400,8 +455,10 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageGab(JN
     const float* in[3] = {(const float*)ADDR(i0), (const float*)ADDR(i1), (const float*)ADDR(i2)};
     float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
     float a[3], b[3];
-    (*e)->GetFloatArrayRegion(e, w1, 0, 3, a);
-    (*e)->GetFloatArrayRegion(e, w2, 0, 3, b);
+    GETF(w1, 3, a);
+    GETF(w2, 3, b);
+    NEED(i0, 4 * area(h, w)); NEED(i1, 4 * area(h, w)); NEED(i2, 4 * area(h, w));
+    NEED(o0, 4 * area(h, w)); NEED(o1, 4 * area(h, w)); NEED(o2, 4 * area(h, w));
     CHECK(jxl_stage_gab(c, in, out, h, w, a, b));
 }
 
@@ -412,7 +469,10 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageEpf(JN
     const float* in[3] = {(const float*)ADDR(i0), (const float*)ADDR(i1), (const float*)ADDR(i2)};
     float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
     float cs[3];
-    (*e)->GetFloatArrayRegion(e, channelScale, 0, 3, cs);
+    GETF(channelScale, 3, cs);
+    NEED(i0, 4 * area(h, w)); NEED(i1, 4 * area(h, w)); NEED(i2, 4 * area(h, w));
+    NEED(o0, 4 * area(h, w)); NEED(o1, 4 * area(h, w)); NEED(o2, 4 * area(h, w));
+    NEED_OPT(invSigma, 4 * area(((jlong)h + 7) / 8, ((jlong)w + 7) / 8));
     CHECK(jxl_stage_epf(c, in, out, h, w, iterations, (const float*)ADDR(invSigma), invSigmaModular, cs, pass0, pass2, borderSadMul));
 }
 
@@ -420,7 +480,8 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageEpfSig
         jint bw, jfloat globalScale, jfloatArray sharpLut, jobject invSigma) {
     jxl_ctx* c = ctx_of(e, self);
     float lut[8];
-    (*e)->GetFloatArrayRegion(e, sharpLut, 0, 8, lut);
+    GETF(sharpLut, 8, lut);
+    NEED(hfMul, 4 * area(bh, bw)); NEED(sharpness, 4 * area(bh, bw)); NEED(invSigma, 4 * area(bh, bw));
     CHECK(jxl_stage_epf_sigma(c, (const int32_t*)ADDR(hfMul), (const int32_t*)ADDR(sharpness), bh, bw, globalScale, lut, (float*)ADDR(invSigma)));
 }
 
@@ -433,8 +494,10 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageLfDequ
     d.lfg_y = lfgY; d.lfg_x = lfgX; d.cells_h = cellsH; d.cells_w = cellsW;
     d.lf_quant[0] = (const int32_t*)ADDR(qX); d.lf_quant[1] = (const int32_t*)ADDR(qY); d.lf_quant[2] = (const int32_t*)ADDR(qB);
     d.extra_precision = extraPrecision;
-    (*e)->GetFloatArrayRegion(e, scaledDequant, 0, 3, d.scaled_dequant);
+    GETF(scaledDequant, 3, d.scaled_dequant);
     d.x_factor_lf = xFactorLF; d.b_factor_lf = bFactorLF; d.adaptive_smoothing = adaptiveSmoothing ? 1 : 0;
+    NEED(qX, 4 * area(cellsH, cellsW)); NEED(qY, 4 * area(cellsH, cellsW)); NEED(qB, 4 * area(cellsH, cellsW));
+    NEED(o0, 4 * area(cellsH, cellsW)); NEED(o1, 4 * area(cellsH, cellsW)); NEED(o2, 4 * area(cellsH, cellsW));
     float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
     CHECK(jxl_stage_lf_dequant(c, &d, baseCorrX, baseCorrB, colorFactor, out));
 }
@@ -444,15 +507,17 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageXyb(JN
     jxl_ctx* c = ctx_of(e, self);
     float* pl[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
     float m[9], b[3], cb[3];
-    (*e)->GetFloatArrayRegion(e, matrix, 0, 9, m);
-    (*e)->GetFloatArrayRegion(e, bias, 0, 3, b);
-    (*e)->GetFloatArrayRegion(e, cbrtBias, 0, 3, cb);
+    GETF(matrix, 9, m);
+    GETF(bias, 3, b);
+    GETF(cbrtBias, 3, cb);
+    NEED(p0, 4 * n); NEED(p1, 4 * n); NEED(p2, 4 * n);
     CHECK(jxl_stage_xyb(c, pl, n, m, b, cb, intensityTarget));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageYcbcr(JNIEnv* e, jobject self, jobject p0, jobject p1, jobject p2, jlong n) {
     jxl_ctx* c = ctx_of(e, self);
     float* pl[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
+    NEED(p0, 4 * n); NEED(p1, 4 * n); NEED(p2, 4 * n);
     CHECK(jxl_stage_ycbcr(c, pl, n));
 }
 
@@ -460,18 +525,21 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageYcbcr(
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageTransfer(JNIEnv* e, jobject self, jobject in, jlong n, jint transfer,
         jint maxValue, jobject outF, jobject outI) {
     jxl_ctx* c = ctx_of(e, self);
+    NEED(in, 4 * n); NEED_OPT(outF, 4 * n); NEED_OPT(outI, 4 * n);
     CHECK(jxl_stage_transfer(c, (const float*)ADDR(in), n, transfer, maxValue, (float*)ADDR(outF), (int32_t*)ADDR(outI)));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageInvHSqueeze(JNIEnv* e, jobject self, jobject avg, jint aw, jobject res,
         jint rw, jint h, jobject out) {
     jxl_ctx* c = ctx_of(e, self);
+    NEED(avg, 4 * area(h, aw)); NEED(res, 4 * area(h, rw)); NEED(out, 4 * area(h, (jlong)aw + rw));
     CHECK(jxl_stage_inv_hsqueeze(c, (const int32_t*)ADDR(avg), aw, (const int32_t*)ADDR(res), rw, h, (int32_t*)ADDR(out)));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageInvVSqueeze(JNIEnv* e, jobject self, jobject avg, jint ah, jobject res,
         jint rh, jint w, jobject out) {
     jxl_ctx* c = ctx_of(e, self);
+    NEED(avg, 4 * area(ah, w)); NEED(res, 4 * area(rh, w)); NEED(out, 4 * area((jlong)ah + rh, w));
     CHECK(jxl_stage_inv_vsqueeze(c, (const int32_t*)ADDR(avg), ah, (const int32_t*)ADDR(res), rh, w, (int32_t*)ADDR(out)));
 }
 
@@ -479,27 +547,38 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageRct(JN
         jint rctType) {
     jxl_ctx* c = ctx_of(e, self);
     int32_t* v[3] = {(int32_t*)ADDR(v0), (int32_t*)ADDR(v1), (int32_t*)ADDR(v2)};
+    NEED(v0, 4 * n); NEED(v1, 4 * n); NEED(v2, 4 * n);
     CHECK(jxl_stage_rct(c, v, n, rctType));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageModularToFloat(JNIEnv* e, jobject self, jobject a, jobject b, jlong n,
         jfloat scale, jobject out) {
     jxl_ctx* c = ctx_of(e, self);
+    NEED(a, 4 * n); NEED_OPT(b, 4 * n); NEED(out, 4 * n);
     CHECK(jxl_stage_modular_to_float(c, (const int32_t*)ADDR(a), (const int32_t*)ADDR(b), n, scale, (float*)ADDR(out)));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageChromaUpsample(JNIEnv* e, jobject self, jobject in, jint h, jint w,
         jint xShift, jint yShift, jobject out) {
     jxl_ctx* c = ctx_of(e, self);
+    if (xShift < 0 || xShift > 1 || yShift < 0 || yShift > 1) { bad_arg(e, "jxlatte_amd: chroma shift"); return; }
+    NEED(in, 4 * area(h, w)); NEED(out, 4 * area((jlong)h << yShift, (jlong)w << xShift));
     CHECK(jxl_stage_chroma_upsample(c, (const float*)ADDR(in), h, w, xShift, yShift, (float*)ADDR(out)));
 }
 
 /* Frame.java:217-260 upsampling weights: packed (the bitstream's / default table) -> k * k * 25 floats */
 JNIEXPORT jfloatArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_upsamplingWeights(JNIEnv* e, jclass k_, jint k, jfloatArray packed) {
     (void)k_;
-    jfloat* p = (*e)->GetFloatArrayElements(e, packed, NULL);
+    /* k first (2, 4 or 8: Frame.java:217), then the packed table's length for that k: 15, 55 or 210 weights */
+    const jsize need = k == 2 ? 15 : k == 4 ? 55 : k == 8 ? 210 : -1;
+    if (need < 0 || !packed || (*e)->GetArrayLength(e, packed) < need) {
+        bad_arg(e, "jxlatte_amd: upsampling factor or packed weight table");
+        return NULL;
+    }
     jfloatArray out = (*e)->NewFloatArray(e, k * k * 25);
-    if (!p || !out) return NULL;
+    if (!out) return NULL;  /* OutOfMemoryError pending */
+    jfloat* p = (*e)->GetFloatArrayElements(e, packed, NULL);
+    if (!p) return NULL;
     jfloat* o = (*e)->GetFloatArrayElements(e, out, NULL);
     const jxl_status st = o ? jxl_upsampling_weights(k, p, o) : JXL_ERR_OOM;
     if (o) (*e)->ReleaseFloatArrayElements(e, out, o, 0);
@@ -511,6 +590,8 @@ JNIEXPORT jfloatArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_upsa
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageUpsample(JNIEnv* e, jobject self, jobject in, jint h, jint w, jint k,
         jfloatArray weights, jobject out) {
     jxl_ctx* c = ctx_of(e, self);
+    if ((k != 2 && k != 4 && k != 8) || !weights || (*e)->GetArrayLength(e, weights) < k * k * 25) { bad_arg(e, "jxlatte_amd: upsampling weights"); return; }
+    NEED(in, 4 * area(h, w)); NEED(out, 4 * area((jlong)h * k, (jlong)w * k));
     jfloat* wt = (*e)->GetFloatArrayElements(e, weights, NULL);
     const jxl_status st = wt ? jxl_stage_upsample(c, (const float*)ADDR(in), h, w, k, wt, (float*)ADDR(out)) : JXL_ERR_OOM;
     if (wt) (*e)->ReleaseFloatArrayElements(e, weights, wt, JNI_ABORT);
@@ -521,6 +602,7 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageNoiseI
         jlong seed0, jint colors, jobject o0, jobject o1, jobject o2) {
     jxl_ctx* c = ctx_of(e, self);
     float* out[3] = {(float*)ADDR(o0), (float*)ADDR(o1), (float*)ADDR(o2)};
+    NEED(o0, 4 * area(h, w)); NEED(o1, 4 * area(h, w)); NEED(o2, 4 * area(h, w));
     CHECK(jxl_stage_noise_init(c, h, w, groupDim, (uint64_t)seed0, colors, out));
 }
 
@@ -530,7 +612,8 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageNoiseA
     float* pl[3] = {(float*)ADDR(p0), (float*)ADDR(p1), (float*)ADDR(p2)};
     const float* nz[3] = {(const float*)ADDR(n0), (const float*)ADDR(n1), (const float*)ADDR(n2)};
     float l[8];
-    (*e)->GetFloatArrayRegion(e, lut, 0, 8, l);
+    GETF(lut, 8, l);
+    NEED(p0, 4 * n); NEED(p1, 4 * n); NEED(p2, 4 * n); NEED(n0, 4 * n); NEED(n1, 4 * n); NEED(n2, 4 * n);
     CHECK(jxl_stage_noise_add(c, pl, nz, n, l, baseCorrX, baseCorrB));
 }
 
@@ -540,7 +623,9 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageBlend(
         jintArray rect) {
     jxl_ctx* c = ctx_of(e, self);
     jint r[8];
-    (*e)->GetIntArrayRegion(e, rect, 0, 8, r);
+    GETI(rect, 8, r);
+    NEED(canvas, 4 * area(ch, cw)); NEED(frame, 4 * area(fh, fw)); NEED_OPT(ref, 4 * area(rh, rw));
+    NEED_OPT(frameAlpha, 4 * area(fh, fw)); NEED_OPT(refAlpha, 4 * area(rh, rw));
     jxl_blend_rect br;
     br.h = r[0]; br.w = r[1]; br.canvas_y = r[2]; br.canvas_x = r[3]; br.frame_y = r[4]; br.frame_x = r[5]; br.ref_y = r[6]; br.ref_x = r[7];
     CHECK(jxl_stage_blend(c, mode, (uint32_t)flags, isInt ? 1 : 0, ADDR(canvas), ch, cw, ADDR(frame), fh, fw, ADDR(ref), rh, rw,
@@ -550,6 +635,7 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageBlend(
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stageOrient(JNIEnv* e, jobject self, jobject in, jint h, jint w, jint orientation,
         jobject out) {
     jxl_ctx* c = ctx_of(e, self);
+    NEED(in, 4 * area(h, w)); NEED(out, 4 * area(h, w));
     CHECK(jxl_stage_orient(c, ADDR(in), h, w, orientation, ADDR(out)));
 }
 
@@ -558,13 +644,21 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_stagePack(J
         jobject out) {
     jxl_ctx* c = ctx_of(e, self);
     jint pv[15];
-    (*e)->GetIntArrayRegion(e, params, 0, 15, pv);
+    GETI(params, 15, pv);
     jxl_pack_params p;
     p.height = pv[0]; p.width = pv[1]; p.n_color = pv[2]; p.has_alpha = pv[3]; p.premultiplied = pv[4]; p.bit_depth = pv[5]; p.big_endian = pv[6];
     for (int i = 0; i < 4; i++) { p.is_int[i] = pv[7 + i]; p.tagged_depth[i] = pv[11 + i]; }
     const void* pl[4] = {NULL, NULL, NULL, NULL};
+    if (!planes || p.n_color < 1 || p.n_color > 3 || (p.bit_depth != 8 && p.bit_depth != 16)) { bad_arg(e, "jxlatte_amd: pack parameters"); return; }
     const jsize n = (*e)->GetArrayLength(e, planes);
-    for (jsize i = 0; i < n && i < 4; i++) pl[i] = ADDR((*e)->GetObjectArrayElement(e, planes, i));
+    const jsize want = p.n_color + (p.has_alpha ? 1 : 0);
+    if (n < want) { bad_arg(e, "jxlatte_amd: pack: fewer planes than channels"); return; }
+    for (jsize i = 0; i < want; i++) {
+        jobject b = (*e)->GetObjectArrayElement(e, planes, i);
+        NEED(b, 4 * area(p.height, p.width));
+        pl[i] = ADDR(b);
+    }
+    NEED(out, area(p.height, p.width) * want * (p.bit_depth / 8));
     CHECK(jxl_stage_pack(c, pl, &p, ADDR(out)));
 }
 
@@ -576,8 +670,7 @@ JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modula
     jint w[256], h[256];
     jxl_squeeze_param sp[64];
     if (n > 256) { rethrow(e, NULL, JXL_ERR_INVALID_ARGUMENT); return NULL; }
-    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
-    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
+    if (!get_ints(e, widths, n, w) || !get_ints(e, heights, n, h)) return NULL;
     const int32_t cnt = jxl_modular_default_squeeze_params((const int32_t*)w, (const int32_t*)h, n, nbMeta, sp, 64);
     if (cnt < 0) { rethrow(e, NULL, (jxl_status)cnt); return NULL; }
     jintArray out = (*e)->NewIntArray(e, cnt * 4);
@@ -597,9 +690,7 @@ JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modula
     int32_t ow[1024], oh[1024];
     jxl_squeeze_param sp[64];
     if (n > 256 || n_sp > 64) { rethrow(e, NULL, JXL_ERR_INVALID_ARGUMENT); return NULL; }
-    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
-    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
-    (*e)->GetIntArrayRegion(e, squeezeParams, 0, n_sp * 4, spv);
+    if (!get_ints(e, widths, n, w) || !get_ints(e, heights, n, h) || !get_ints(e, squeezeParams, n_sp * 4, spv)) return NULL;
     for (jsize i = 0; i < n_sp; i++) {
         sp[i].horizontal = spv[4 * i]; sp[i].in_place = spv[4 * i + 1]; sp[i].begin_c = spv[4 * i + 2]; sp[i].num_c = spv[4 * i + 3];
     }
@@ -624,12 +715,15 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularBegi
     jxl_channel ci[256];
     jxl_squeeze_param sp[64];
     jint w[256], h[256], spv[256];
-    (*e)->GetIntArrayRegion(e, widths, 0, n, w);
-    (*e)->GetIntArrayRegion(e, heights, 0, n, h);
-    (*e)->GetIntArrayRegion(e, squeezeParams, 0, n_sp * 4, spv);
+    GETI(widths, n, w);
+    GETI(heights, n, h);
+    GETI(squeezeParams, n_sp * 4, spv);
     for (jsize i = 0; i < n; i++) {
+        jobject b = (*e)->GetObjectArrayElement(e, chans, i);
+        if ((*e)->ExceptionCheck(e)) return;
         ci[i].width = w[i]; ci[i].height = h[i];
-        ci[i].data = (int32_t*)ADDR((*e)->GetObjectArrayElement(e, chans, i));
+        if (area(h[i], w[i]) > 0) NEED(b, 4 * area(h[i], w[i]));  /* (an empty channel may come without a buffer) */
+        ci[i].data = (int32_t*)ADDR(b);
     }
     for (jsize i = 0; i < n_sp; i++) {
         sp[i].horizontal = spv[4 * i]; sp[i].in_place = spv[4 * i + 1]; sp[i].begin_c = spv[4 * i + 2]; sp[i].num_c = spv[4 * i + 3];
@@ -658,6 +752,9 @@ JNIEXPORT jintArray JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modula
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_modularReadChannel(JNIEnv* e, jobject self, jint idx, jobject dst) {
     jxl_ctx* c = ctx_of(e, self);
+    int32_t cw = 0, chh = 0;
+    CHECK(jxl_modular_out_shape(c, idx, &cw, &chh));
+    NEED(dst, 4 * area(chh, cw));
     CHECK(jxl_modular_read_channel(c, idx, (int32_t*)ADDR(dst)));
 }
 
