@@ -372,7 +372,7 @@ def main():
     # the bench; the figures are carried over only when workload and variant match, else null.
     traffic, valu_insts, traffic_src = None, None, None
     src_sha = kernel_source_sha()
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if args.workload == "vardct4k" and epf_iters == 2 and args.mix == "default" and os.path.exists(tpath):
             try:
@@ -464,7 +464,7 @@ def kernel_source_sha():
     """sha256 over the sources of the dominant kernel (the stamp of profiles/rN_traffic.json)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("k_restore_fused.hip", "restore_sink.h", "jxl_fastpow.h"):
+    for f in ("k_restore_fused.hip", "restore_fused_body.h", "restore_sink.h", "jxl_fastpow.h"):
         with open(os.path.join(ROOT, "jxlatte_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

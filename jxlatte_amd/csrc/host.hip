@@ -74,41 +74,6 @@ struct ModChan {
 
 }  // namespace
 
-// Host-side frame grids that are uploaded every frame live in page-locked memory: hipMemcpyAsync from pageable memory goes
-// through a staging copy and returns only when it is done (ten uploads of ~0.5 MB cost 0.3 ms of jxl_vardct_prepare), from
-// page-locked memory it is a queued DMA. Falls back to malloc where page-locking fails (then it is merely slower).
-template <class T>
-struct PinnedAlloc {
-    typedef T value_type;
-    PinnedAlloc() = default;
-    template <class U>
-    PinnedAlloc(const PinnedAlloc<U>&) {}
-    T* allocate(size_t n) {
-        void* p = nullptr;
-        const size_t bytes = n * sizeof(T) + 16;
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
-            *static_cast<uint64_t*>(p) = 1;
-        } else {
-            (void)hipGetLastError();
-            p = malloc(bytes);
-            if (!p) throw std::bad_alloc();
-            *static_cast<uint64_t*>(p) = 0;
-        }
-        return reinterpret_cast<T*>(static_cast<char*>(p) + 16);
-    }
-    void deallocate(T* q, size_t) {
-        void* p = reinterpret_cast<char*>(q) - 16;
-        if (*static_cast<uint64_t*>(p)) (void)hipHostFree(p);
-        else free(p);
-    }
-    template <class U>
-    bool operator==(const PinnedAlloc<U>&) const { return true; }
-    template <class U>
-    bool operator!=(const PinnedAlloc<U>&) const { return false; }
-};
-template <class T>
-using pinned_vector = std::vector<T, PinnedAlloc<T>>;
-
 // a typed window of the table staging buffer (jxl_ctx::h_tab)
 template <class T>
 struct HSpan {

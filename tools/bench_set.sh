@@ -1,6 +1,6 @@
 #!/bin/bash
 # the round's bench figures, each the verbatim JSON line of the named command (GPU box): bash tools/r3_bench_set.sh r3
-R=${1:-r3}
+R=${1:-r4}
 O=gpurun_out/bench_$R
 mkdir -p $O
 L=tests/golden/samples_large
