@@ -50,6 +50,9 @@ typedef const __attribute__((address_space(4))) v2f* cv2fp;
 typedef const __attribute__((address_space(4))) v4i* cv4ip;
 
 __constant__ float kLlfScale3[32] = JXL_LLF_SCALE_INIT;
+// LDS behind the block images: [3][64] dequantisation table | [104] finalizeLLF tables | [192] LF patches | [3][256] scaleFactor[c] / m
+constexpr int kWg3AuxFloats = 3 * 64 + 104 + 192;
+constexpr int kWg3SfEntries = 256;
 
 // Diagnostic build only (-DJXL_STAMPS): lane 0 of every workgroup records s_memtime at the phase boundaries of its first
 // two items (rows 2*wg and 2*wg+1 of the stamp buffer)
@@ -447,8 +450,26 @@ struct Body {
             const int g = tid + C::T * j;
             const int b = g / C::GPB, r = g % C::GPB;
             const int n = r / (W / 4), x4 = (r % (W / 4)) * 4;
-            // scaleFactor[c] / hfMultiplier (HFCoefficients.java:299)
-            const float sf[3] = {f.scale_factor[0] / raw.hfm[j], f.scale_factor[1] / raw.hfm[j], f.scale_factor[2] / raw.hfm[j]};
+            // scaleFactor[c] / hfMultiplier (HFCoefficients.java:299): the same IEEE quotient, formed once per workgroup and
+            // multiplier value (sf_tab, r4) instead of three divisions per group of four samples
+            float sf[3];
+            {
+                const int hi = (int)raw.hfm[j];
+                const float* sft = qtab + kWg3AuxFloats;
+#ifdef JXL_WG3_SF_DIV  // A/B build: the three divisions per group (r1-r3)
+                if (false) {
+#else
+                if (__builtin_expect((unsigned)hi < (unsigned)kWg3SfEntries, 1)) {
+#endif
+                    sf[0] = sft[hi];
+                    sf[1] = sft[kWg3SfEntries + hi];
+                    sf[2] = sft[2 * kWg3SfEntries + hi];
+                } else {
+                    sf[0] = f.scale_factor[0] / raw.hfm[j];
+                    sf[1] = f.scale_factor[1] / raw.hfm[j];
+                    sf[2] = f.scale_factor[2] / raw.hfm[j];
+                }
+            }
             // (element access by constant index after unrolling: copying the vectors into local arrays made the compiler load
             // them as one <12 x float> and keep the whole prefetch state in scratch memory)
 #define QV(c, i) (raw.q[j][c][i])
@@ -679,6 +700,10 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     float* lf_patch = aux + 104;
     if (tid0 < 70) aux[tid0] = a.f.lut[tid0];
     else if (tid0 >= 72 && tid0 < 104) aux[tid0] = kLlfScale3[tid0 - 72];
+    for (int i = tid0; i < 3 * kWg3SfEntries; i += T) {  // hfMultiplier values 1 .. 255 (larger ones divide in place)
+        const int c = i / kWg3SfEntries, m = i % kWg3SfEntries;
+        qtab[kWg3AuxFloats + i] = a.f.scale_factor[c] / (float)(m > 0 ? m : 1);
+    }
     Raw<NG, WS> raw;
     Recs<NG> rc;
     load_recs<T, NG>(a, cur, tid0, rc);
@@ -982,8 +1007,8 @@ int64_t wg3_llf_count(const Wg3Args& a) {
     return n;
 }
 
-// block images + dequantisation table [3][64] + finalizeLLF tables (cosine LUT 70 + 2, LLF scale 32, LF patches 192)
-size_t wg3_lds_bytes(const Wg3Args& a) { return sizeof(float) * ((size_t)a.img_floats + 3 * 64 + 104 + 192); }
+// block images + dequantisation table [3][64] + finalizeLLF tables (cosine LUT 70 + 2, LLF scale 32, LF patches 192) + scale table [3][256]
+size_t wg3_lds_bytes(const Wg3Args& a) { return sizeof(float) * ((size_t)a.img_floats + kWg3AuxFloats + 3 * kWg3SfEntries); }
 
 // batch forms: dev_args[0..n_frames) in device memory; max_llf = the largest wg3_llf_count, grid_x workgroups per frame,
 // lds = the largest wg3_lds_bytes among the frames
