@@ -43,7 +43,7 @@ for f in glob.glob("$OUT/v_$name/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         dur[r['Kernel_Name'][:70]].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1000)
 for k,v in acc.items():
-    if 'restore' in k or 'idct' in k:
+    if 'restore' in k:
         d=sorted(dur[k]); print("  %-72s us %.1f  %s" % (k, d[len(d)//2] if d else -1, {c:'%.4g'%(sum(x)/len(x)) for c,x in v.items()}))
 PY
   fi
