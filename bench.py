@@ -353,6 +353,13 @@ def main():
     e2e = None
     if not args.no_end_to_end and distinct and args.workload == "vardct4k":
         try:
+            # the timed batch is over and every figure of it has been read: its contexts (8 frames' planes, 16+ streams on the
+            # process's 4 hardware queues) go before the boundary legs create their own -- with them alive the streaming leg
+            # measured 3.0 Gpx/s at 8 contexts against 5.0 in a process of its own (tools/r4_stream_ctx_sweep.sh)
+            frames.clear()
+            for c in ctxs:
+                c.close()
+            ctxs.clear()
             e2e = end_to_end_leg(_lib, abi, host, synth, distinct[0], local_rank, npx)
         except Exception as e:
             e2e = {"error": repr(e)[:300]}
@@ -684,7 +691,7 @@ def synth_num_groups(d):
     return synth.num_groups(d)
 
 
-def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "12")), frames_per_ctx=8):
+def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "8")), frames_per_ctx=8):
     import threading
     lib = _lib.load()
     coeff16 = [np.ascontiguousarray(a, np.int16) for a in d["coeff"]]
@@ -693,6 +700,8 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
     pouts = [host.PinnedArray(lib, ref_out.shape, ref_out.dtype) for _ in range(n_ctx)]
     start = threading.Barrier(n_ctx + 1)
     errs, same, t_end = [], [True] * n_ctx, [0.0] * n_ctx
+    phases = [np.zeros(8) for _ in range(n_ctx)]  # host time per call, summed per context
+    t_beg, t_loop = [0.0] * n_ctx, [0.0] * n_ctx
 
     def worker(i):
         c = ctxs[i]
@@ -704,28 +713,34 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
             def one_frame():
                 # frame k+1's host share (begin ... commit) runs while frame k's kernels and output copy are in flight on the
                 # same context: read_output is split into begin (queued) and wait (before the output buffer is reused)
-                fr = host.Frame(c, p, d["weights"], d["woffs"])
+                t = [time.perf_counter()]
+                fr = host.Frame(c, p, d["weights"], d["woffs"]); t.append(time.perf_counter())
                 for g in d["lfgroups"]:
                     fr.setLFGroup(g)
-                c.call("jxl_vardct_prepare")
-                mp = fr.mapCoeffsI16(no_fill=True)
+                t.append(time.perf_counter())
+                c.call("jxl_vardct_prepare"); t.append(time.perf_counter())
+                mp = fr.mapCoeffsI16(no_fill=True); t.append(time.perf_counter())
                 for ch in range(3):
                     np.copyto(mp[ch], coeff16[ch])  # stands for the entropy decoder's stores (every group, zeros included)
-                fr.commitCoeffsI16(all_groups)
+                t.append(time.perf_counter())
+                fr.commitCoeffsI16(all_groups); t.append(time.perf_counter())
                 if state["pending"]:
                     c.call("jxl_vardct_read_output_wait")  # frame k's pixels have landed: the buffer is free again
-                fr.run()
-                c.call("jxl_vardct_read_output_begin", pp, fr.width)
+                fr.run(); t.append(time.perf_counter())
+                c.call("jxl_vardct_read_output_begin", pp, fr.width); t.append(time.perf_counter())
                 state["pending"] = True
+                phases[i] += np.diff(t)
             one_frame()  # allocations, page-locking
             c.call("jxl_vardct_read_output_wait")
             state["pending"] = False
+            phases[i][:] = 0.0
             start.wait()
+            t_beg[i] = time.perf_counter()
             for _ in range(frames_per_ctx):
                 one_frame()
+            t_loop[i] = time.perf_counter()
             c.call("jxl_vardct_read_output_wait")
-            t_end[i] = time.perf_counter()  # (the comparison below is the bench's own check, not the boundary's work)
-            same[i] = bool(np.array_equal(pouts[i].array, ref_out))
+            t_end[i] = time.perf_counter()
         except Exception as e:  # noqa: BLE001
             errs.append(repr(e)[:200])
             try:
@@ -742,6 +757,12 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
         for t in th:
             t.join()
         wall = (max(t_end) if min(t_end) > 0.0 else time.perf_counter()) - a
+        # the bench's own check, not the boundary's work -- and made only when every thread has finished: a 25 MB comparison in
+        # the thread that finishes first costs the threads still running their share of the host's memory system (r4)
+        same = [bool(np.array_equal(x.array, ref_out)) for x in pouts]
+        if os.environ.get("JXL_BENCH_STREAM_DEBUG"):
+            print("stream debug: a->beg %s  beg->loop %s  loop->end %s" % (["%.1f" % ((x - a) * 1e3) for x in t_beg], ["%.1f" % ((y - x) * 1e3) for x, y in zip(t_beg, t_loop)],
+                                                                          ["%.1f" % ((y - x) * 1e3) for x, y in zip(t_loop, t_end)]), file=sys.stderr)
     finally:
         for t in th:
             t.join()
@@ -754,6 +775,8 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
     n = n_ctx * frames_per_ctx
     return {"contexts": n_ctx, "frames": n, "wall_ms": round(wall * 1e3, 2), "ms_per_frame": round(wall * 1e3 / n, 3),
             "streaming_end_to_end_Mpx_s": round(npx * n / wall / 1e6, 1), "identical_output": all(same),
+            "host_ms_per_frame_and_thread": dict(zip(("begin", "lfgroups", "prepare", "map", "stores", "commit", "wait_prev+run", "read_begin"),
+                                                     [round(float(v), 2) for v in sum(phases) / n * 1e3])),
             "note": "%d contexts, one host thread each: begin_frame + LF groups + prepare + map (no zero-fill: every group is written) + "
                     "coefficient stores + commit (3 DMA transfers of int16 planes) + run + read_output_begin per frame, read_output_wait "
                     "one frame later (RGB8); all frames through the whole boundary; PCIe-inclusive, never `value`" % n_ctx}

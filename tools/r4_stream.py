@@ -3,6 +3,10 @@ profiling:  python tools/r4_stream.py [n_ctx] [frames_per_ctx]    -> wall time p
 import ctypes as C, os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get("R4_STREAM_TORCH"):  # what does the bench process have that this one lacks? 1: torch imported, 2: + CUDA initialised + a sync
+    import torch
+    if os.environ["R4_STREAM_TORCH"] == "2":
+        torch.cuda.set_device(0); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
 from jxlatte_amd import _lib, abi, host, synth
 
 n_ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 12
