@@ -288,3 +288,51 @@ def test_mapped_planes_without_zero_fill_and_split_read_output(ctx, orc):
     assert_bits_equal(f2.decodeFrame(), exp_full, "all groups written, no zero-fill")
     with pytest.raises(_lib.JxlError):
         f2.readOutputWait()  # nothing begun
+
+
+@pytest.mark.gpu
+def test_groups_never_put_read_as_zero_also_on_a_reused_context(ctx, orc):
+    """begin_frame gives a frame fresh coefficient planes (HFCoefficients.java:68: new int[..]); since r4 the zero-fill is deferred
+    until something needs it. A frame whose caller puts only some groups must see zeros in the others -- also when the context
+    has just run another frame whose coefficients are still in the planes, through the per-group entries (int32 and int16) and
+    when no group is put at all"""
+    fr = synth.make_vardct_frame(520, 520, seed=80, aligned=False)  # 3 x 3 groups
+    p = abi.VarDCTParams.from_buffer_copy(fr["params"])
+    p.stages = abi.STAGE_IDCT | abi.STAGE_GAB | abi.STAGE_EPF
+    full = orc.vardct_frame(fr, stages=p.stages)
+
+    def frame(put, i16=False):
+        f = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+        for g in fr["lfgroups"]:
+            f.setLFGroup(g)
+        for grp in put:
+            q = synth.group_view(fr, grp)
+            if i16:
+                f.putGroupI16(0, grp, [np.ascontiguousarray(a, np.int16) for a in q])
+            else:
+                f.putGroup(0, grp, q)
+        return f.decodeFrame()
+
+    def expected(put):
+        z = dict(fr)
+        z["coeff"] = np.zeros_like(fr["coeff"])
+        for grp in put:
+            gy, gx = divmod(grp, 3)
+            z["coeff"][:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256] = fr["coeff"][:, gy * 256:(gy + 1) * 256, gx * 256:(gx + 1) * 256]
+        return orc.vardct_frame(z, stages=p.stages)
+
+    assert_bits_equal(frame(range(9)), full, "every group put")
+    assert_bits_equal(frame([0, 4, 8]), expected([0, 4, 8]), "three groups put behind a full frame on the same context")
+    assert_bits_equal(frame([]), expected([]), "no group put at all")
+    assert_bits_equal(frame(range(9), i16=True), full, "every group put (int16)")
+    assert_bits_equal(frame([1, 5], i16=True), expected([1, 5]), "two groups put (int16) behind a full frame")
+    # mapped planes committed, then a later frame with per-group puts only
+    f = host.Frame(ctx, p, fr["weights"], fr["woffs"])
+    for g in fr["lfgroups"]:
+        f.setLFGroup(g)
+    planes = f.mapCoeffsI16(no_fill=True)
+    for c in range(3):
+        planes[c][...] = fr["coeff"][c]
+    f.commitCoeffsI16(np.ones(9, np.uint8))
+    assert_bits_equal(f.decodeFrame(), full, "mapped planes")
+    assert_bits_equal(frame([2]), expected([2]), "one group put behind a frame committed from mapped planes")
