@@ -72,7 +72,28 @@ L += ["", "IDCT stage kernels: SQ_WAIT_ANY share of the wave cycles (waves parke
 for k in sorted(dur, key=lambda k: -dur[k]):
     if k.startswith(("k_idct", "k_llf")) and k in sq:
         L.append("* `%s`: %.0f %% (%.1f us per launch)" % (k, 100 * sq[k].get("SQ_WAIT_ANY", 0) / max(sq[k].get("SQ_WAVE_CYCLES", 1), 1), dur[k]))
-rk = [k for k in dur if k.startswith("k_restore_fused")][0]
+# read over-fetch of the IDCT launches: FETCH_SIZE (x2: gfx950 counts a 128-byte request as 64) against the coefficient bytes the
+# launch's varblock types own (12 bytes per pixel of their area share; the share comes from the bench line of the same round)
+share_path = os.path.join(out_dir, "%s_bench_vardct4k.json" % tag)
+if os.path.exists(share_path):
+    try:
+        cfg = json.loads(open(share_path).read().strip().splitlines()[-1])["config"]["varblock_area_share"]
+        cls = {"k_idct_wg3<false>": ("DCT8", "DCT16", "DCT32", "DCT16_8", "DCT8_16", "DCT32_8", "DCT8_32", "DCT32_16", "DCT16_32"),
+               "k_idct_wg3<true>": ("DCT64", "DCT64_32", "DCT32_64"),
+               "k_idct_special_wg": ("HORNUSS", "DCT2", "DCT4", "DCT4_8", "DCT8_4", "AFV0", "AFV1", "AFV2", "AFV3")}
+        L += ["", "Coefficient reads of the IDCT launches (4K frame = 99.5 MB of int32 coefficients; FETCH_SIZE doubled as the guide prescribes):", "",
+              "| launch | area share | coefficient bytes used (MB) | fetched (MB) | ratio |", "|---|---|---|---|---|"]
+        for k, types in cls.items():
+            if k not in fetch:
+                continue
+            sh = sum(cfg.get(t, 0.0) for t in types)
+            used = sh * 12.0 * 3840 * 2160 / 1e6
+            got = 2 * fetch[k]["FETCH_SIZE"] * 1024 / 1e6
+            L.append("| `%s` | %.3f | %.1f | %.1f | %.2f |" % (k, sh, used, got, got / used if used else 0))
+        L += ["", "(the fetched figure includes the weight rows, block records and LF samples of the items: 1-3 MB per launch)"]
+    except Exception as e:  # noqa: BLE001
+        L += ["", "(over-fetch table not produced: %r)" % (e,)]
+rk = sorted([k for k in dur if k.startswith("k_restore_fused")], key=lambda k: (", 0, 1>" not in k, -dur[k]))[0]  # the float-plane variant
 fk, wk = fetch[rk]["FETCH_SIZE"], write[rk]["WRITE_SIZE"]
 traffic = {"kernel": rk, "fetch_KiB": fk, "write_KiB": wk, "launch_us_profiled": dur[rk], "fetch_bytes_raw": fk * 1024, "write_bytes": wk * 1024,
            "hbm_bytes_per_launch": 2 * fk * 1024 + wk * 1024,
