@@ -263,32 +263,38 @@ jxl_status bind(jxl_ctx* ctx) {
     return JXL_OK;
 }
 
-__global__ void k_accumulate2d(int32_t* dst, int64_t dpitch, const int32_t* src, int gw, int gh) {
+// The writers of the coefficient planes. The C ABI hands over raster planes; the device planes are tiled by 8x8 cell
+// (coeff_off, jxl_internal.h), so every writer places sample (y0 + y, x0 + x) of a plane W wide through coeff_off.
+// int32 group rectangle (src: gw x gh, dense) -> plane; acc: the passes after the first add (PassGroup.java:174-200, Java int wrap)
+__global__ void k_store2d_tiled(int32_t* plane, int W, int y0, int x0, const int32_t* src, int gw, int gh, int acc) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= gw || y >= gh) return;
-    int32_t* d = dst + (int64_t)y * dpitch + x;
-    *d = (int32_t)((uint32_t)*d + (uint32_t)src[(int64_t)y * gw + x]);  // PassGroup.java:174-200
+    int32_t* d = plane + coeff_off(W, y0 + y, x0 + x);
+    const int32_t v = src[(int64_t)y * gw + x];
+    *d = acc ? (int32_t)((uint32_t)*d + (uint32_t)v) : v;
 }
 
-// int16 wire format -> the int32 coefficient planes (acc: PassGroup.java:174-200, Java int wrap)
-__global__ void k_widen2d(int32_t* dst, int64_t dpitch, const int16_t* src, int gw, int gh, int acc) {
+// int16 wire format -> the int32 coefficient planes
+__global__ void k_widen2d(int32_t* plane, int W, int y0, int x0, const int16_t* src, int gw, int gh, int acc) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= gw || y >= gh) return;
-    int32_t* d = dst + (int64_t)y * dpitch + x;
+    int32_t* d = plane + coeff_off(W, y0 + y, x0 + x);
     const int32_t v = (int32_t)src[(int64_t)y * gw + x];
     *d = acc ? (int32_t)((uint32_t)*d + (uint32_t)v) : v;
 }
 
-// The same from page-locked HOST memory (r4: jxl_vardct_commit_coeffs_i16 without the staging copy): every lane moves 8 samples --
-// one 16-byte read over PCIe, two 16-byte stores -- so that the transfer is made of full-size read requests and needs no SDMA
-// transfer, no device staging buffer and no host API call per plane besides this launch. gw % 8 == 0.
-__global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ dst, int64_t dpitch, const int16_t* __restrict__ src, int gw, int gh) {
-    const int x8 = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x8 * 8 >= gw || y >= gh) return;
+// The same for a whole plane from page-locked HOST memory (r4: jxl_vardct_commit_coeffs_i16 without the staging copy): every lane
+// moves 8 samples -- one 16-byte read over PCIe, two 16-byte stores (one cell row) -- so that the transfer is made of full-size
+// read requests and needs no SDMA transfer, no device staging buffer and no host API call per plane besides this launch.
+// gw % 8 == 0, gh % 8 == 0. A workgroup takes 32 cells of a cell row: 32 consecutive lanes read 512 consecutive bytes of one
+// sample row (the PCIe side keeps its long runs), the 8 rows of the workgroup complete every cell it touches.
+__global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ plane, const int16_t* __restrict__ src, int gw, int gh) {
+    const int r = threadIdx.x >> 5, bx = blockIdx.x * 32 + (threadIdx.x & 31), by = blockIdx.y;
+    if (bx * 8 >= gw) return;
     typedef int v4i_ __attribute__((ext_vector_type(4)));
-    const v4i_ pk = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(src + (int64_t)y * gw + x8 * 8));
-    int32_t* d = dst + (int64_t)y * dpitch + x8 * 8;
+    const v4i_ pk = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(src + (int64_t)(by * 8 + r) * gw + bx * 8));
+    int32_t* d = plane + (((int64_t)by * (gw >> 3) + bx) << 6) + r * 8;
     *reinterpret_cast<v4i_*>(d) = v4i_{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
     *reinterpret_cast<v4i_*>(d + 4) = v4i_{(pk.z << 16) >> 16, pk.z >> 16, (pk.w << 16) >> 16, pk.w >> 16};
 }
@@ -1462,16 +1468,14 @@ jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const i
         // channel geometry (HFCoefficients.java:64-69, PassGroup.java:223-226): all shifts are zero for ordinary frames
         const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
         if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
-        int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)((gy * 256) >> c->sy[ch]) * Wc + ((gx * 256) >> c->sx[ch]);
+        const int y0 = (gy * 256) >> c->sy[ch], x0 = (gx * 256) >> c->sx[ch];
         const bool pinned = is_pinned_host(q[ch]);
-        if (pass == 0) {
-            HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)Wc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
-        } else {
-            HIP_TRY(c, hipMemcpy2DAsync(c->group_tmp.p, (size_t)gwc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(k_accumulate2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, dst, (int64_t)Wc,
-                               c->group_tmp.as<int32_t>(), gwc, ghc);
-            if (pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));  // group_tmp is reused by the next plane
-        }
+        // the rectangle is staged densely and placed by a kernel: the device planes are tiled by cell, which no 2-D copy
+        // can express (the staging tile is reused in stream order)
+        int32_t* tmp = c->group_tmp.as<int32_t>();
+        HIP_TRY(c, hipMemcpy2DAsync(tmp, (size_t)gwc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_store2d_tiled, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), Wc, y0,
+                           x0, tmp, gwc, ghc, pass > 0 ? 1 : 0);
         if (!pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller's buffer is pageable and may be reused
     }
     return JXL_OK;
@@ -1495,11 +1499,12 @@ jxl_status jxl_vardct_put_group_i16(jxl_ctx* c, int32_t pass, int32_t group, con
     for (int ch = 0; ch < 3; ch++) {
         const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
         if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
-        int32_t* dst = c->coeff[ch].as<int32_t>() + (size_t)((gy * 256) >> c->sy[ch]) * Wc + ((gx * 256) >> c->sx[ch]);
+        const int y0 = (gy * 256) >> c->sy[ch], x0 = (gx * 256) >> c->sx[ch];
         int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + tile * ((size_t)group * 3 + ch));
         const bool pinned = is_pinned_host(q[ch]);
         HIP_TRY(c, hipMemcpy2DAsync(stg, (size_t)gwc * 2, q[ch], (size_t)stride[ch] * 2, (size_t)gwc * 2, ghc, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, dst, (int64_t)Wc, stg, gwc, ghc, pass > 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), Wc, y0, x0, stg, gwc, ghc,
+                           pass > 0 ? 1 : 0);
         if (!pinned || pass > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));  // pageable source; a later pass reuses the slot
     }
     return JXL_OK;
@@ -1581,8 +1586,8 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
         static const bool zero_copy = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
         void* hdev = nullptr;
         if (zero_copy && (Wc & 7) == 0 && hipHostGetDevicePointer(&hdev, c->h_map16, 0) == hipSuccess && hdev) {
-            hipLaunchKernelGGL(k_widen2d_host8, dim3(ceil_div(Wc / 8, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(),
-                               (int64_t)Wc, reinterpret_cast<const int16_t*>(static_cast<char*>(hdev) + off), Wc, Hc);
+            hipLaunchKernelGGL(k_widen2d_host8, dim3(ceil_div(Wc / 8, 32), Hc / 8), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(),
+                               reinterpret_cast<const int16_t*>(static_cast<char*>(hdev) + off), Wc, Hc);
             off += (bytes + 255) & ~(size_t)255;
             continue;
         }
@@ -1590,8 +1595,8 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
         if (!c->stage16.ensure(c->h_map16_bytes)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
         int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + off);
         HIP_TRY(c, hipMemcpyAsync(stg, static_cast<char*>(c->h_map16) + off, bytes, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(Wc, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), (int64_t)Wc, stg,
-                           Wc, Hc, 0);
+        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(Wc, 64), ceil_div(Hc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), Wc, 0, 0, stg, Wc,
+                           Hc, 0);
         off += (bytes + 255) & ~(size_t)255;
     }
     c->coeff_zero_pending = false;  // every sample of the three planes has just been written

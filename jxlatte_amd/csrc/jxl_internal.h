@@ -60,6 +60,16 @@ struct DevFrame {
     float color_factor_f;     // (float)colorFactor
 };
 
+// Layout of the quantised-coefficient planes on the device (r4): tiled by 8x8 cell. The 64 samples of cell (by, bx) of a
+// plane W samples wide are consecutive, row-major, at ((by * (W / 8) + bx) * 64 -- a varblock's rows then share cache lines
+// (an 8x8 block is two whole 128-byte lines instead of eight quarter lines), which is what the launches that handle one
+// transform type at a time need: in a raster plane they fetched 1.5-3.7 times the bytes they used (profiles/r4_rocprof_summary).
+// The C ABI still speaks raster planes; the writers (k_store2d_tiled / k_widen2d* in host.hip) do the re-tiling. Runs of up to
+// 8 samples that start at a multiple of 4 (8) stay inside one cell row, so 16- and 32-byte loads are unaffected.
+__host__ __device__ __forceinline__ int64_t coeff_off(int W, int py, int px) {
+    return (((int64_t)(py >> 3) * (W >> 3) + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));
+}
+
 __host__ __device__ inline int lut_off(int l) {
     // sum_{j<l} (2^j - 1) * 2^j
     int o = 0;

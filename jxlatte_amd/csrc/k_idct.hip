@@ -347,15 +347,14 @@ __device__ __forceinline__ void cfl_factors(const DevFrame& f, int ty, int tx, b
 template <int PI, bool FLIP>
 __device__ __forceinline__ void small_row(const DevFrame& f, int c, int y, int64_t base, float hfm, float kc, float lf_c,
                                           float co[8]) {
-    const int W = f.width;
     const float qbn = f.quant_bias_numerator;
     auto load8 = [&](int ch, int q[8]) {
 #ifdef JXL_ABL_SPECIAL_NOLOAD  // timing experiment: every lane reads the frame's first rows (always cached)
-        const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + (int64_t)y * W + (threadIdx.x & 7) * 8);
-        const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + (int64_t)y * W + (threadIdx.x & 7) * 8 + 4);
+        const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + (threadIdx.x & 7) * 64 + y * 8);
+        const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + (threadIdx.x & 7) * 64 + y * 8 + 4);
 #else
-        const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + base + (int64_t)y * W);
-        const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + base + (int64_t)y * W + 4);
+        const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + base + y * 8);  // (cell-tiled plane: coeff_off)
+        const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + base + y * 8 + 4);
 #endif
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
     };
@@ -400,7 +399,7 @@ __device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock 
         const float lf_c = f.lf[c][b.cy * f.bw + b.cx];
         float co[64], px[64];
 #pragma unroll
-        for (int y = 0; y < 8; y++) small_row<PI, false>(f, c, y, base, hfm, kc, lf_c, co + y * 8);
+        for (int y = 0; y < 8; y++) small_row<PI, false>(f, c, y, coeff_off(W, py0, px0), hfm, kc, lf_c, co + y * 8);
         invert_small<TYPE>(co, px);
 #ifdef JXL_ABL_SPECIAL_NOSTORE  // timing experiment: the lanes of a wave store 64 consecutive blocks' worth at the frame's start
         float* o = (c == 0 ? o0 : c == 1 ? o1 : o2) + (int64_t)(blockIdx.x & 15) * 8 * W + threadIdx.x * 8;
@@ -460,7 +459,7 @@ __device__ __forceinline__ void dequant_sample(const DevFrame& f, const BlockCtx
         dq[0] = dq[1] = dq[2] = 0.0f;
         return;
     }
-    const int64_t off = (int64_t)(k.py0 + y) * f.width + k.px0 + x;
+    const int64_t off = coeff_off(f.width, k.py0 + y, k.px0 + x);
     const int wy = k.flip ? x : y, wx = k.flip ? y : x;
     const int wi = wy * k.mw + wx;
     const float dy = dequant1(f.coeff[1][off], f.quant_bias[1], f.quant_bias_numerator, k.sfc[1], k.w[1][wi]);
@@ -478,7 +477,7 @@ __device__ __forceinline__ void dequant_sample(const DevFrame& f, const BlockCtx
 // one channel of dequant_sample (luma is dequantised again for the chroma channels)
 __device__ __forceinline__ float dequant_sample_c(const DevFrame& f, const BlockCtx& k, int c, int y, int x) {
     if (y < k.dsh && x < k.dsw) return 0.0f;
-    const int64_t off = (int64_t)(k.py0 + y) * f.width + k.px0 + x;
+    const int64_t off = coeff_off(f.width, k.py0 + y, k.px0 + x);
     const int wy = k.flip ? x : y, wx = k.flip ? y : x;
     const int wi = wy * k.mw + wx;
     const float dy = dequant1(f.coeff[1][off], f.quant_bias[1], f.quant_bias_numerator, k.sfc[1], k.w[1][wi]);
@@ -659,13 +658,14 @@ __device__ __forceinline__ void medium_item(const DevFrame& f, const DevBlock* _
             for (int n0 = 0; n0 < H; n0 += RC) {
                 int qcv[RC], qyv[RC];
                 float wcv[RC], wyv[RC];
-                const int64_t off0 = (int64_t)(py0 + n0) * FW + px0 + x;
+                static_assert(RC == 4 || RC == 8, "a chunk of rows stays inside one cell row of the tiled plane");
+                const int64_t off0 = coeff_off(FW, py0 + n0, px0 + x);
 #pragma unroll
                 for (int r = 0; r < RC; r++) {
-                    qcv[r] = qc_plane[off0 + (int64_t)r * FW];
+                    qcv[r] = qc_plane[off0 + r * 8];
                     wcv[r] = wc[(n0 + r) * W + x];  // (FLIP ? transposed table : table)[n][x]
                     if (c != 1 && !f.no_cfl) {
-                        qyv[r] = qy_plane[off0 + (int64_t)r * FW];
+                        qyv[r] = qy_plane[off0 + r * 8];
                         wyv[r] = wy[(n0 + r) * W + x];
                     }
                 }
@@ -780,10 +780,11 @@ __device__ __forceinline__ void medium_item3(const DevFrame& f, const DevBlock* 
             for (int n0 = 0; n0 < H; n0 += RC) {
                 int qcv[RC];
                 float wcv[RC];
-                const int64_t off0 = (int64_t)(py0 + n0) * FW + px0 + x;
+                static_assert(RC == 4 || RC == 8, "a chunk of rows stays inside one cell row of the tiled plane");
+                const int64_t off0 = coeff_off(FW, py0 + n0, px0 + x);
 #pragma unroll
                 for (int r = 0; r < RC; r++) {
-                    qcv[r] = qc_plane[off0 + (int64_t)r * FW];
+                    qcv[r] = qc_plane[off0 + r * 8];
                     wcv[r] = wc[(n0 + r) * W + x];  // (FLIP ? transposed table : table)[n][x]
                 }
 #pragma unroll
@@ -915,7 +916,7 @@ __device__ __forceinline__ void wg64_item(const DevFrame& f, const DevBlock* __r
             wcv[j] = wyv[j] = 0.0f;
             if (bi < nb) {
                 const DevBlock b = load_block(blocks, (int)it.first + bi);
-                const int64_t off = (int64_t)(b.cy * 8 + n) * FW + b.cx * 8 + x;
+                const int64_t off = coeff_off(FW, b.cy * 8 + n, b.cx * 8 + x);
                 qcv[j] = f.coeff[c][off];
                 wcv[j] = wc[n * W + x];
                 if (c != 1 && !f.no_cfl) {
@@ -1261,7 +1262,7 @@ __device__ __forceinline__ void special_wg_body(const DevFrame& f, const DevBloc
             const DevBlock b = load_block(blocks, (int)it.first + blk);
             gx[k] = (int)b.cy | ((int)b.cx << 16);
             hfm[k] = (float)b.hf_mul;
-            const int64_t off = (int64_t)(b.cy * 8 + row) * W + b.cx * 8 + half * 4;
+            const int64_t off = coeff_off(W, b.cy * 8 + row, b.cx * 8 + half * 4);  // (the block's 16 lanes: 256 consecutive bytes)
 #pragma unroll
             for (int c = 0; c < 3; c++) q[k][c] = *reinterpret_cast<const v4i_t*>(f.coeff[c] + off);
             cfl_factors(f, (b.cy * 8) >> 6, (b.cx * 8) >> 6, b.cfl_zero & 1u, kx[k], kb[k]);

@@ -160,7 +160,7 @@ __device__ __forceinline__ void wave_request(const WaveArgs& a, int nb, int lane
             const int cy = breci[b * 8], cx = breci[b * 8 + 1];
             const uint32_t cfl_zero = (uint32_t)breci[b * 8 + 2];
             const int py = cy * 8 + n, px = cx * 8 + x4;
-            const int64_t goff = (int64_t)py * f.width + px;
+            const int64_t goff = coeff_off(f.width, py, px);
             raw.q[j][0] = *reinterpret_cast<const v4i*>(f.coeff[1] + goff);
             raw.q[j][1] = *reinterpret_cast<const v4i*>(f.coeff[0] + goff);
             raw.q[j][2] = *reinterpret_cast<const v4i*>(f.coeff[2] + goff);
@@ -453,7 +453,7 @@ __device__ __forceinline__ void wave_big(const WaveArgs& a, int type, int first,
                 gbm |= 1 << j;
                 const int cy = breci[b * 8], cx = breci[b * 8 + 1];
                 const int py = cy * 8 + n, px = cx * 8 + x4;
-                q[j] = *reinterpret_cast<const v4i*>(qp + (int64_t)py * f.width + px);
+                q[j] = *reinterpret_cast<const v4i*>(qp + coeff_off(f.width, py, px));
                 if (ci > 0) {
                     const uint32_t cfl_zero = (uint32_t)breci[b * 8 + 2];
                     const int ty = py >> 6, tx = px >> 6;

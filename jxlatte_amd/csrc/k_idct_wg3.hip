@@ -400,11 +400,11 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             const uint32_t cfl_zero = (uint32_t)rc.gz[j];
             raw.hfm[j] = (float)rc.gw[j];
             const int py = cy * 8 + n, px = cx * 8 + x4;
-            const int64_t off = (int64_t)py * f.width + px;
-            if (a.coeff16[0]) {  // (uniform) 8 bytes per group and channel, widened here
+            const int64_t off = coeff_off(f.width, py, px);  // cell-tiled int32 planes
+            if (a.coeff16[0]) {  // (uniform) 8 bytes per group and channel, widened here; the staged int16 planes are raster
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const v2i pk = *reinterpret_cast<const v2i*>(a.coeff16[c] + off);
+                    const v2i pk = *reinterpret_cast<const v2i*>(a.coeff16[c] + (int64_t)py * f.width + px);
                     raw.q[j][c] = v4i{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
                 }
             } else {
