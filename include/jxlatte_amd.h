@@ -196,7 +196,11 @@ jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* ctx, const jxl_lfquant_desc* 
 
 /* quantizedCoeffs of one (pass, group) (HFCoefficients.java:43,68): q[c] is [gh][gw] with row
  * stride[c] elements; gh,gw = Frame.getGroupSize(group). pass > 0 accumulates
- * (PassGroup.java:174-200). */
+ * (PassGroup.java:174-200).
+ * Buffer lifetime: pageable sources (and page-locked ones that are not 16-byte aligned in address and row stride) are copied
+ * before the call returns and may be reused at once. Aligned page-locked sources (jxl_host_alloc) are read by the device in
+ * place, asynchronously: keep them unchanged until jxl_vardct_run / finish_frame of this frame has returned or
+ * jxl_ctx_synchronize has. The call itself never waits for the device except when more than 8 puts are still in flight. */
 jxl_status jxl_vardct_put_group(jxl_ctx* ctx, int32_t pass, int32_t group,
                                 const int32_t* const q[3], const int32_t stride[3]);
 /* The same with 16-bit samples -- the wire format for the PCIe leg: quantised HF coefficients of photographic content fit

@@ -99,7 +99,7 @@ struct jxl_ctx {
     jxl_vardct_params p{};
     int W = 0, H = 0, bw = 0, bh = 0, tw = 0, th = 0;
     DevBuf coeff[3], lf[3], llf[3], weights_t, hf_mul, sharp, xfy, bfy, weights, planeA[3], planeB[3], outbuf[3], inv_sigma, blocks, items,
-        group_tmp, bad_flag;
+        bad_flag;
     int32_t woffs[51]{};
     // Per-frame tables (r4): ONE page-locked staging buffer laid out like ONE device arena, ONE transfer per prepare. The
     // fixed-size grids (hfMultiplier, sharpness, CfL factors per tile, LF planes: sizes known at begin_frame) come first and the
@@ -176,7 +176,14 @@ struct jxl_ctx {
     bool out_inflight = false;
     size_t h_map16_bytes = 0;
     bool map16_valid = false;
-    DevBuf stage16;            // int16 wire format: one tile per (group, channel) (jxl_vardct_put_group_i16)
+    DevBuf stage16;            // the committed int16 planes on the device (the staged form of jxl_vardct_commit_coeffs_i16)
+    // page-locked staging ring of jxl_vardct_put_group*: one slot = the three rectangles of a group
+    static constexpr int kGrpSlots = 8;
+    void* h_grp = nullptr;
+    const void* h_grp_dev = nullptr;
+    hipEvent_t grp_ev[kGrpSlots] = {};
+    bool grp_inflight[kGrpSlots] = {};
+    int grp_slot = 0;
     std::vector<float> h_weights_in;  // the last weight set handed over (set_weights skips an identical one)
     int32_t h_woffs_in[51] = {};
     DevBuf wg3_items[2];       // spatially ordered item lists of the two k_idct_wg3 classes (wg3_item_table)
@@ -265,14 +272,42 @@ jxl_status bind(jxl_ctx* ctx) {
 
 // The writers of the coefficient planes. The C ABI hands over raster planes; the device planes are tiled by 8x8 cell
 // (coeff_off, jxl_internal.h), so every writer places sample (y0 + y, x0 + x) of a plane W wide through coeff_off.
-// int32 group rectangle (src: gw x gh, dense) -> plane; acc: the passes after the first add (PassGroup.java:174-200, Java int wrap)
-__global__ void k_store2d_tiled(int32_t* plane, int W, int y0, int x0, const int32_t* src, int gw, int gh, int acc) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= gw || y >= gh) return;
-    int32_t* d = plane + coeff_off(W, y0 + y, x0 + x);
-    const int32_t v = src[(int64_t)y * gw + x];
-    *d = acc ? (int32_t)((uint32_t)*d + (uint32_t)v) : v;
+// One (pass, group) of all three channels in one launch, read straight from page-locked HOST memory (the caller's buffers when
+// they are page-locked and 16-byte aligned, else the context's staging ring): a lane moves 8 samples of one row -- 16 (int16) or
+// 32 (int32) bytes over PCIe, one 32-byte cell row into the tiled plane. acc: the passes after the first add
+// (PassGroup.java:174-200, Java int wrap). Replaces a 2-D copy + a kernel (+ a host wait) per CHANNEL (r1-r3).
+struct PutGroupArgs {
+    int32_t* plane[3];
+    const void* src[3];
+    int32_t sstride[3];  // elements
+    int32_t W[3], y0[3], x0[3], gw[3], gh[3];
+    int32_t acc;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_put_group(const PutGroupArgs a) {
+    const int ch = blockIdx.z;
+    const int r = threadIdx.x >> 5, bx = blockIdx.x * 32 + (threadIdx.x & 31), by = blockIdx.y;
+    if (bx * 8 >= a.gw[ch] || by * 8 >= a.gh[ch]) return;
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const T* sp = static_cast<const T*>(a.src[ch]) + (int64_t)(by * 8 + r) * a.sstride[ch] + bx * 8;
+    v4i_ lo, hi;
+    if constexpr (sizeof(T) == 2) {
+        const v4i_ pk = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sp));
+        lo = v4i_{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
+        hi = v4i_{(pk.z << 16) >> 16, pk.z >> 16, (pk.w << 16) >> 16, pk.w >> 16};
+    } else {
+        lo = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sp));
+        hi = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sp) + 1);
+    }
+    int32_t* d = a.plane[ch] + coeff_off(a.W[ch], a.y0[ch] + by * 8 + r, a.x0[ch] + bx * 8);
+    if (a.acc) {
+        const v4i_ l0 = *reinterpret_cast<v4i_*>(d), h0 = *reinterpret_cast<v4i_*>(d + 4);
+        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+        lo = (v4i_)((v4u_)lo + (v4u_)l0);
+        hi = (v4i_)((v4u_)hi + (v4u_)h0);
+    }
+    *reinterpret_cast<v4i_*>(d) = lo;
+    *reinterpret_cast<v4i_*>(d + 4) = hi;
 }
 
 // int16 wire format -> the int32 coefficient planes
@@ -297,15 +332,6 @@ __global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ pla
     int32_t* d = plane + (((int64_t)by * (gw >> 3) + bx) << 6) + r * 8;
     *reinterpret_cast<v4i_*>(d) = v4i_{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
     *reinterpret_cast<v4i_*>(d + 4) = v4i_{(pk.z << 16) >> 16, pk.z >> 16, (pk.w << 16) >> 16, pk.w >> 16};
-}
-
-bool is_pinned_host(const void* p) {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();  // an ordinary malloc pointer: not an error of ours
-        return false;
-    }
-    return at.type == hipMemoryTypeHost;
 }
 
 bool is_small(int t) { return JXL_TT[t].ph == 8 && JXL_TT[t].pw == 8; }
@@ -1136,7 +1162,7 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->lut, &c->hf_mul, &c->sharp, &c->xfy, &c->bfy, &c->weights, &c->weights_t, &c->inv_sigma, &c->blocks, &c->items,
-                     &c->group_tmp, &c->bad_flag};
+                     &c->bad_flag};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 3; i++) {
         c->coeff[i].release(); c->lf[i].release(); c->llf[i].release(); c->lfq_tmp[i].release(); c->planeA[i].release(); c->planeB[i].release(); c->outbuf[i].release();
@@ -1148,6 +1174,9 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     c->srgb16_tab.release();
     c->tab.release();
     if (c->tab_ev) (void)hipEventDestroy(c->tab_ev);
+    for (int i = 0; i < jxl_ctx::kGrpSlots; i++)
+        if (c->grp_ev[i]) (void)hipEventDestroy(c->grp_ev[i]);
+    if (c->h_grp) (void)hipHostFree(c->h_grp);
     if (c->h_tab) {
         if (c->h_tab_pinned) (void)hipHostFree(c->h_tab);
         else free(c->h_tab);
@@ -1242,7 +1271,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
         if (out_interleaved(p->out_format)) ok = ok && (i > 0 || c->outbuf[0].ensure(3 * (size_t)out_elem_size(p->out_format) * npx));
         else if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
     }
-    ok = ok && c->inv_sigma.ensure(4 * nc) && c->group_tmp.ensure(4 * 256 * 256) && tab_begin_frame(c, nc, nt);
+    ok = ok && c->inv_sigma.ensure(4 * nc) && tab_begin_frame(c, nc, nt);
     if (!ok) return fail(c, JXL_ERR_OOM, "device allocation failed for a %dx%d frame", c->W, c->H);
     c->coeff_zero_pending = true;  // new int[sY][sX] (HFCoefficients.java:68): zeroed when a group is put / the frame runs
     c->out_zero_pending = true;    // frame buffer starts zeroed (ImageBuffer ctor): zeroed at run time if a cell has no varblock
@@ -1454,60 +1483,91 @@ static jxl_status pre_run_zero(jxl_ctx* c) {
     return zero_output_planes(c);
 }
 
-jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const int32_t* const q[3], const int32_t stride[3]) {
+// device-visible address of page-locked host memory (null: pageable)
+static const void* pinned_device_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc pointer: not an error of ours
+        return nullptr;
+    }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+
+// jxl_vardct_put_group / _i16. The group's three rectangles go to the device in ONE launch that reads host memory itself
+// (k_put_group): page-locked, 16-byte aligned caller buffers are read in place (the caller keeps them until the stream has
+// passed this point -- jxl_ctx_synchronize or a finished frame -- as with the queued copies of r2-r3); anything else is copied
+// by the host into a small page-locked ring first, after which the caller's buffer is free at once and nothing waits
+// until the ring wraps onto a slot whose launch has not finished.
+extern "C++" {
+template <typename T>
+static jxl_status put_group_t(jxl_ctx* c, int32_t pass, int32_t group, const T* const q[3], const int32_t stride[3]) {
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
     c->coeff16_resident = false;
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
-    if ((st = zero_coeff_planes(c))) return st;
     const int gy = group / grs, gx = group % grs;  // Frame.getGroupLocation (Frame.java:883)
     const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);  // getGroupSize (:905)
+    PutGroupArgs a;
+    a.acc = pass > 0 ? 1 : 0;
+    bool in_place = true;
     for (int ch = 0; ch < 3; ch++) {
         // channel geometry (HFCoefficients.java:64-69, PassGroup.java:223-226): all shifts are zero for ordinary frames
-        const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
-        if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
-        const int y0 = (gy * 256) >> c->sy[ch], x0 = (gx * 256) >> c->sx[ch];
-        const bool pinned = is_pinned_host(q[ch]);
-        // the rectangle is staged densely and placed by a kernel: the device planes are tiled by cell, which no 2-D copy
-        // can express (the staging tile is reused in stream order)
-        int32_t* tmp = c->group_tmp.as<int32_t>();
-        HIP_TRY(c, hipMemcpy2DAsync(tmp, (size_t)gwc * 4, q[ch], (size_t)stride[ch] * 4, (size_t)gwc * 4, ghc, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_store2d_tiled, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), Wc, y0,
-                           x0, tmp, gwc, ghc, pass > 0 ? 1 : 0);
-        if (!pinned) HIP_TRY(c, hipStreamSynchronize(c->stream));  // caller's buffer is pageable and may be reused
+        a.gw[ch] = gw >> c->sx[ch];
+        a.gh[ch] = gh >> c->sy[ch];
+        a.W[ch] = c->W >> c->sx[ch];
+        a.y0[ch] = (gy * 256) >> c->sy[ch];
+        a.x0[ch] = (gx * 256) >> c->sx[ch];
+        a.plane[ch] = c->coeff[ch].as<int32_t>();
+        if (!q[ch] || stride[ch] < a.gw[ch]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
+        a.sstride[ch] = stride[ch];
+        a.src[ch] = nullptr;
+        if (in_place && (((uintptr_t)q[ch] | ((uintptr_t)stride[ch] * sizeof(T))) & 15) == 0) a.src[ch] = pinned_device_ptr(q[ch]);
+        in_place = in_place && a.src[ch];
     }
+    if ((st = zero_coeff_planes(c))) return st;
+    if (!in_place) {
+        constexpr size_t kSlot = 3 * (size_t)256 * 256 * sizeof(int32_t);
+        if (!c->h_grp) {
+            if (hipHostMalloc(&c->h_grp, kSlot * jxl_ctx::kGrpSlots, hipHostMallocDefault) != hipSuccess || !c->h_grp) {
+                (void)hipGetLastError();
+                c->h_grp = nullptr;
+                return fail(c, JXL_ERR_OOM, "page-locked allocation of the group staging ring failed");
+            }
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, c->h_grp, 0) != hipSuccess || !dp) return fail(c, JXL_ERR_DEVICE, "no device address for the group staging ring");
+            c->h_grp_dev = dp;
+            for (int i = 0; i < jxl_ctx::kGrpSlots; i++) HIP_TRY(c, hipEventCreateWithFlags(&c->grp_ev[i], hipEventDisableTiming));
+        }
+        const int slot = c->grp_slot;
+        c->grp_slot = (slot + 1) % jxl_ctx::kGrpSlots;
+        if (c->grp_inflight[slot]) HIP_TRY(c, hipEventSynchronize(c->grp_ev[slot]));
+        c->grp_inflight[slot] = false;
+        for (int ch = 0; ch < 3; ch++) {
+            const size_t o = kSlot * slot + (size_t)ch * 256 * 256 * sizeof(int32_t);
+            T* d = reinterpret_cast<T*>(static_cast<char*>(c->h_grp) + o);
+            for (int y = 0; y < a.gh[ch]; y++) memcpy(d + (size_t)y * a.gw[ch], q[ch] + (size_t)y * stride[ch], sizeof(T) * (size_t)a.gw[ch]);
+            a.src[ch] = static_cast<const char*>(c->h_grp_dev) + o;
+            a.sstride[ch] = a.gw[ch];
+        }
+        hipLaunchKernelGGL(k_put_group<T>, dim3(ceil_div(gw / 8, 32), gh / 8, 3), dim3(256), 0, c->stream, a);
+        HIP_TRY(c, hipEventRecord(c->grp_ev[slot], c->stream));
+        c->grp_inflight[slot] = true;
+    } else {
+        hipLaunchKernelGGL(k_put_group<T>, dim3(ceil_div(gw / 8, 32), gh / 8, 3), dim3(256), 0, c->stream, a);
+    }
+    HIP_TRY(c, hipGetLastError());
     return JXL_OK;
+}
+}  // extern "C++"
+
+jxl_status jxl_vardct_put_group(jxl_ctx* c, int32_t pass, int32_t group, const int32_t* const q[3], const int32_t stride[3]) {
+    return put_group_t<int32_t>(c, pass, group, q, stride);
 }
 
 jxl_status jxl_vardct_put_group_i16(jxl_ctx* c, int32_t pass, int32_t group, const int16_t* const q[3], const int32_t stride[3]) {
-    jxl_status st = bind(c);
-    if (st) return st;
-    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
-    c->coeff16_resident = false;
-    const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
-    if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
-    if ((st = zero_coeff_planes(c))) return st;
-    const int gy = group / grs, gx = group % grs;
-    const int gh = std::min(256, c->H - gy * 256), gw = std::min(256, c->W - gx * 256);
-    // staging: one 256 x 256 int16 tile per (group, channel) in a ring large enough for a frame, so that the copies of a
-    // frame's groups queue up behind each other without a host wait when the source is page-locked
-    const size_t tile = (size_t)256 * 256 * sizeof(int16_t);
-    const size_t slots = (size_t)grs * gcs * 3;
-    if (!c->stage16.ensure(tile * slots)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
-    for (int ch = 0; ch < 3; ch++) {
-        const int gwc = gw >> c->sx[ch], ghc = gh >> c->sy[ch], Wc = c->W >> c->sx[ch];
-        if (!q[ch] || stride[ch] < gwc) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad plane %d", ch);
-        const int y0 = (gy * 256) >> c->sy[ch], x0 = (gx * 256) >> c->sx[ch];
-        int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + tile * ((size_t)group * 3 + ch));
-        const bool pinned = is_pinned_host(q[ch]);
-        HIP_TRY(c, hipMemcpy2DAsync(stg, (size_t)gwc * 2, q[ch], (size_t)stride[ch] * 2, (size_t)gwc * 2, ghc, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_widen2d, dim3(ceil_div(gwc, 64), ceil_div(ghc, 4)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(), Wc, y0, x0, stg, gwc, ghc,
-                           pass > 0 ? 1 : 0);
-        if (!pinned || pass > 0) HIP_TRY(c, hipStreamSynchronize(c->stream));  // pageable source; a later pass reuses the slot
-    }
-    return JXL_OK;
+    return put_group_t<int16_t>(c, pass, group, q, stride);
 }
 
 jxl_status jxl_vardct_map_coeffs_i16_ex(jxl_ctx* c, int16_t* planes[3], int32_t strides[3], int32_t flags) {

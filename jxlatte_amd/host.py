@@ -182,19 +182,29 @@ class Frame:
         d = abi.make_lfquant_desc(q, scaledDequant, extraPrecision, xFactorLF, bFactorLF, adaptiveSmoothing, lfg_y, lfg_x)
         self.ctx.call("jxl_vardct_set_lfgroup_lfquant", C.byref(d))
 
+    @staticmethod
+    def _rows(a, dt):
+        """a 2-D plane as the ABI takes it: samples of a row consecutive, rows `stride` elements apart -- views with a row
+        stride (a rectangle of a larger plane, page-locked or not) are passed as they are, anything else is made contiguous"""
+        a = np.asarray(a)
+        if a.dtype != dt or a.ndim != 2 or a.strides[1] != a.itemsize or a.strides[0] % a.itemsize or a.strides[0] < a.shape[1] * a.itemsize:
+            a = np.ascontiguousarray(a, dt)
+        return a
+
     def putGroup(self, pass_, group, q):
-        q = [np.ascontiguousarray(a, np.int32) for a in q]
-        pp = (C.POINTER(C.c_int32) * 3)(*[abi.iptr(a) for a in q])
-        strides = (C.c_int32 * 3)(*[a.shape[1] for a in q])
+        q = [self._rows(a, np.int32) for a in q]
+        pp = (C.POINTER(C.c_int32) * 3)(*[a.ctypes.data_as(C.POINTER(C.c_int32)) for a in q])
+        strides = (C.c_int32 * 3)(*[a.strides[0] // 4 for a in q])
         self.ctx.call("jxl_vardct_put_group", pass_, group, pp, strides)
+        self._keep = getattr(self, "_keep", []) + [q]  # aligned page-locked sources are read in place: keep them alive until run()
 
     def putGroupI16(self, pass_, group, q):
         """the int16 wire format (jxl_vardct_put_group_i16): the caller has checked that every |q| fits"""
-        q = [np.ascontiguousarray(a, np.int16) for a in q]
+        q = [self._rows(a, np.int16) for a in q]
         pp = (C.POINTER(C.c_int16) * 3)(*[a.ctypes.data_as(C.POINTER(C.c_int16)) for a in q])
-        strides = (C.c_int32 * 3)(*[a.shape[1] for a in q])
+        strides = (C.c_int32 * 3)(*[a.strides[0] // 2 for a in q])
         self.ctx.call("jxl_vardct_put_group_i16", pass_, group, pp, strides)
-        self._keep = getattr(self, "_keep", []) + [q]  # page-locked sources are read asynchronously: keep them alive until run()
+        self._keep = getattr(self, "_keep", []) + [q]  # aligned page-locked sources are read in place: keep them alive until run()
 
     def mapCoeffsI16(self, no_fill=False):
         """the frame's three coefficient planes as numpy views over the library's page-locked staging buffer

@@ -168,10 +168,12 @@ def test_sparse_coefficients_and_signed_zero_lf(ctx, orc, mix, aligned, nonzero_
 
 # ---- the PCIe leg: int16 wire format and page-locked buffers ---------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("pinned", [False, True, "misaligned"])
 def test_int16_wire_format_and_pinned_buffers(ctx, orc, pinned):
-    """jxl_vardct_put_group_i16 (+ page-locked sources from jxl_host_alloc, copied asynchronously) fills the same coefficient
-    planes as jxl_vardct_put_group: identical frame output, also for a second pass that accumulates (PassGroup.java:174-200)"""
+    """jxl_vardct_put_group_i16 (+ page-locked sources from jxl_host_alloc, which the device reads in place when they are
+    16-byte aligned -- "misaligned": a page-locked source that is not, which goes through the staging ring like pageable
+    memory; 12 puts wrap the ring of 8) fills the same coefficient planes as jxl_vardct_put_group: identical frame output,
+    also for a second pass that accumulates (PassGroup.java:174-200)"""
     from jxlatte_amd import _lib
     fr = synth.make_vardct_frame(520, 264, seed=77, aligned=False)
     assert np.abs(fr["coeff"]).max() < 32768
@@ -191,11 +193,12 @@ def test_int16_wire_format_and_pinned_buffers(ctx, orc, pinned):
                 part = [(a - 3 * (passes - 1) if ps == 0 else np.full_like(a, 3)) for a in planes]
                 if pinned:
                     dt = np.int16 if use16 else np.int32
-                    pa = [host.PinnedArray(lib, a.shape, dt) for a in part]
+                    pad = 1 if pinned == "misaligned" else 0
+                    pa = [host.PinnedArray(lib, (a.shape[0], a.shape[1] + pad), dt) for a in part]
                     for dst, a in zip(pa, part):
-                        dst.array[...] = a
+                        dst.array[:, pad:] = a
                     keep.extend(pa)
-                    part = [x.array for x in pa]
+                    part = [x.array[:, pad:] for x in pa]
                 if use16:
                     f.putGroupI16(ps, grp, part)
                 else:
