@@ -167,7 +167,6 @@ struct jxl_ctx {
     // 10 = k_llf_wg3, 11 / 12 = k_idct_wg3<false / true> (Wg3Args blocks in batch_wg3_args; grid_x of 10 = lanes)
     struct BatchLaunch { int cls, n_frames, grid_x; size_t lds_bytes, offset; };
     DevBuf batch_wg3_args;
-    bool coeff16_resident = false;  // stage16 holds the whole frame's committed int16 planes and nothing was put since (JXL_WG3_I16)
     void* h_map16 = nullptr;   // page-locked frame-sized int16 planes handed to the caller (jxl_vardct_map_coeffs_i16)
     bool map16_nofill = false;       // mapped without zero-fill: commit must be told which groups were written
     hipEvent_t map16_ev = nullptr;   // "the commit's transfers have read h_map16": what the next map waits for (not the whole stream)
@@ -1285,7 +1284,6 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     c->tables_dirty = true;
     c->frame_open = true;
     c->map16_valid = false;
-    c->coeff16_resident = false;
     c->ev_runs = 0;
     c->result[0] = c->result[1] = c->result[2] = nullptr;
     return JXL_OK;
@@ -1504,7 +1502,6 @@ static jxl_status put_group_t(jxl_ctx* c, int32_t pass, int32_t group, const T* 
     jxl_status st = bind(c);
     if (st) return st;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
-    c->coeff16_resident = false;
     const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
     if (group < 0 || group >= grs * gcs || pass < 0 || !q || !stride) return fail(c, JXL_ERR_INVALID_ARGUMENT, "bad group/pass");
     const int gy = group / grs, gx = group % grs;  // Frame.getGroupLocation (Frame.java:883)
@@ -1642,7 +1639,7 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
         // r4: the widening kernel reads the page-locked planes over PCIe itself -- no SDMA transfer, no device staging copy, one
         // runtime call per plane instead of two. With a dozen contexts committing from a dozen threads the hipMemcpyAsync calls
         // had become the slowest part of a frame (commit 2-3 ms per frame and thread against 0.06; tools/r4_zerocopy_ab.sh).
-        // JXL_COMMIT_ZEROCOPY=0: the staged form (and what JXL_WG3_I16 needs: the int16 planes resident on the device)
+        // JXL_COMMIT_ZEROCOPY=0: the staged form
         static const bool zero_copy = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
         void* hdev = nullptr;
         if (zero_copy && (Wc & 7) == 0 && hipHostGetDevicePointer(&hdev, c->h_map16, 0) == hipSuccess && hdev) {
@@ -1663,8 +1660,6 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
     if (!c->map16_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->map16_ev, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->map16_ev, c->stream));
     c->map16_inflight = true;
-    static const bool zc = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
-    c->coeff16_resident = !c->sub && !zc;  // (the device staging copy of the int16 planes: not made by the zero-copy form)
     return JXL_OK;
 }
 
@@ -1755,14 +1750,6 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                     wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
                     if (wn[tl.cls - 2] < 0) return fail(c, JXL_ERR_STATE, "IDCT launch: too many segments");
                     if (c->wg3_item_count[tl.cls - 2] == wn[tl.cls - 2]) wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
-                    static const bool wg3_i16 = getenv("JXL_WG3_I16") && atoi(getenv("JXL_WG3_I16")) != 0;
-                    if (wg3_i16 && c->coeff16_resident) {  // experiment: the prefetch reads the committed int16 planes
-                        size_t off = 0;
-                        for (int ch = 0; ch < 3; ch++) {
-                            wa[tl.cls - 2].coeff16[ch] = reinterpret_cast<const int16_t*>(static_cast<const char*>(c->stage16.p) + off);
-                            off += ((size_t)c->W * c->H * sizeof(int16_t) + 255) & ~(size_t)255;
-                        }
-                    }
                     all.insert(all.end(), tl.segs.begin(), tl.segs.end());
                 }
             if (!all.empty()) {

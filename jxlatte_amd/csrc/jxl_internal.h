@@ -119,9 +119,6 @@ struct Wg3Args {
     int n_seg, total_items;
     int img_floats;  // floats of the largest three-channel LDS image among the segments' types (the tables follow it)
     int llf_in_item;  // 1: the items transform their blocks' LF patches themselves (finalizeLLF); 0: k_llf_wg3 ran before (llf planes)
-    // experiment (JXL_WG3_I16=1, r3): the committed int16 wire-format planes (row stride = frame width) read directly by the
-    // prefetch instead of the int32 planes k_widen2d makes of them; null: int32 planes (DevFrame::coeff)
-    const int16_t* coeff16[3];
     // optional explicit item list (16-byte records {type, first_block, n_blocks, 0}, total_items of them) in the order the
     // workgroups should take them -- spatial, see wg3_item_table; nullptr: the items follow from the segments, type by type
     const int* items;

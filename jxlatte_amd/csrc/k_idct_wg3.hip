@@ -41,12 +41,31 @@ namespace jxl {
 
 namespace {
 
+// Two adjacent outputs of a lane. JXL_WG3_SCALAR_MAC: a plain pair of floats instead of the 2-vector the packed instructions
+// take (A/B build, r4): v_pk_mul_f32 reads its broadcast sample as a 64-bit register pair whose upper half is undefined, the
+// register allocator parks any live value there -- e.g. a register of the next item's prefetch -- and the wait-count pass then
+// makes the first multiply of the column pass wait for that load (s_waitcnt vmcnt(0)); the scalar form has no such false
+// dependency but needs 15-20 % more cycles in the MAC loops.
+#ifndef JXL_WG3_SCALAR_MAC
 typedef float v2f __attribute__((ext_vector_type(2)));
+// LUT pair j of a wave-uniform slice: ONE 8-byte scalar load into an aligned SGPR pair the packed multiply takes as it is
+// (built from two scalar floats the pair goes through two v_mov per use: +700 instructions in the kernel, measured)
+__device__ __forceinline__ v2f lut_pair(const __attribute__((address_space(4))) float* lr, int j) {
+    return ((const __attribute__((address_space(4))) v2f*)lr)[j];
+}
+#else
+struct v2f {
+    float x, y;
+};
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f lut_pair(const __attribute__((address_space(4))) float* lr, int j) { return v2f{lr[2 * j], lr[2 * j + 1]}; }
+#endif
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) float* cfloatp;
-typedef const __attribute__((address_space(4))) v2f* cv2fp;
 typedef const __attribute__((address_space(4))) v4i* cv4ip;
 
 __constant__ float kLlfScale3[32] = JXL_LLF_SCALE_INIT;
@@ -58,18 +77,29 @@ constexpr int kWg3SfEntries = 256;
 // two items (rows 2*wg and 2*wg+1 of the stamp buffer)
 #ifdef JXL_STAMPS
 __device__ unsigned long long* g_stamps3 = nullptr;
+// (r4) the stamps of items kStampItem and kStampItem + 1 (steady state, not the cold first items) are collected in LDS and written
+// out when the workgroup ends: a stamp that stores to memory reads the buffer pointer with a vector load and waits
+// vmcnt(0) -- for every load in flight, i.e. it MEASURED the prefetch latency into whichever phase it closed (r2-r3 stamps did)
+constexpr int kStampItem = 3;
+__shared__ unsigned long long g_stamp_lds[24];
 #define STAMP3(i)                                                                                                        \
     do {                                                                                                                 \
-        if (g_stamps3 && threadIdx.x == 0 && it_no < 2) g_stamps3[((size_t)blockIdx.x * 2 + it_no) * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && (unsigned)(it_no - kStampItem) < 2u) g_stamp_lds[(it_no - kStampItem) * 12 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
-// workgroup lifetime: entry time, exit time and items done in column 11 of the workgroup's two rows + a third table behind them
+// workgroup lifetime: entry time, exit time and items done in column 11 of the workgroup's two rows
 #define STAMP3_LIFE(row, val)                                                                                            \
     do {                                                                                                                 \
-        if (g_stamps3 && threadIdx.x == 0) g_stamps3[((size_t)blockIdx.x * 2 + (row)) * 12 + 11] = (val);                  \
+        if (threadIdx.x == 0) g_stamp_lds[(row) * 12 + 11] = (val);                                                      \
+    } while (0)
+#define STAMP3_FLUSH()                                                                                                   \
+    do {                                                                                                                 \
+        if (g_stamps3 && threadIdx.x == 0)                                                                               \
+            for (int q_ = 0; q_ < 24; q_++) g_stamps3[(size_t)blockIdx.x * 24 + q_] = g_stamp_lds[q_];                   \
     } while (0)
 #else
 #define STAMP3(i)
 #define STAMP3_LIFE(row, val)
+#define STAMP3_FLUSH()
 #endif
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() carries a workgroup-scope release fence over ALL address
@@ -163,9 +193,9 @@ __device__ __forceinline__ void load_blk(Blk<KC>& b, cfloatp lut /* row n0-1, th
                                          const float* p1, const float* p2, int stride) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-        const cv2fp lr = (cv2fp)(lut + u * N);
+        const cfloatp lr = lut + u * N;  // (scalar loads: the slice is wave-uniform)
 #pragma unroll
-        for (int j = 0; j < KC / 4; j++) b.l[u][j] = lr[j];
+        for (int j = 0; j < KC / 4; j++) b.l[u][j] = lut_pair(lr, j);
         b.s[u][0] = p0[u * stride];
         b.s[u][1] = p1[u * stride];
         b.s[u][2] = p2[u * stride];
@@ -201,9 +231,9 @@ __device__ __forceinline__ void idct1d3(Acc3<KC>& acc, cfloatp lut /* row 0, lan
         v2f l[3][KC / 4];
 #pragma unroll
         for (int u = 0; u < 3; u++) {
-            const cv2fp lr = (cv2fp)(lut + u * N);
+            const cfloatp lr = lut + u * N;
 #pragma unroll
-            for (int j = 0; j < KC / 4; j++) l[u][j] = lr[j];
+            for (int j = 0; j < KC / 4; j++) l[u][j] = lut_pair(lr, j);
             s[u][0] = p0[(u + 1) * stride];
             s[u][1] = p1[(u + 1) * stride];
             s[u][2] = p2[(u + 1) * stride];
@@ -342,6 +372,7 @@ struct Raw {
     float kx[NG], kb[NG];  // CfL factors of the group's 64x64 tile (0 where the reference's cache reads 0)
     float hfm[NG];         // (float)hfMultiplier of the group's block
     float llf;             // lanes < NLLF: one LF sample of the item's blocks (llf_in_item; else the LLF coefficient from the llf planes)
+    int rowx;              // DevBlock word 0 (cy | cx << 16) of the block whose row this lane stores in the row pass
     uint32_t ok;           // bit j: group j belongs to a block of the item
 };
 
@@ -374,7 +405,20 @@ __device__ __forceinline__ void load_recs(const Wg3Args& a, const Item& it, int 
     if (it.type >= 0 && bl < it.nb) rc.lx = ((const __attribute__((address_space(4))) int*)a.blocks)[4 * (it.first + bl)];
 }
 
-// issue every load of item `it` this lane will need at dequantisation time (type-generic: run-time geometry)
+// a wave-uniform pointer to global memory, held in SGPRs and opaque to the optimiser from here on (the address space is
+// kept: a generic pointer would turn the loads into flat_load, which also counts on lgkmcnt -- the LDS waits of the passes
+// would then wait for the prefetch)
+template <typename P>
+__device__ __forceinline__ const __attribute__((address_space(1))) P* sgpr_ptr(const P* p) {
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+s"(u));
+    return (const __attribute__((address_space(1))) P*)u;
+}
+
+// issue every load of item `it` this lane will need at dequantisation time (type-generic: run-time geometry).
+// r4: nothing in here may WAIT for memory. The r3 form indexed the kernel-argument block with the lane's channel to pick the
+// LF plane of its LLF sample -- a per-lane pointer load followed by s_waitcnt vmcnt(0). The plane pointers are now scalar
+// arguments selected with v_cndmask, and the argument words the requests need are pinned in SGPRs.
 template <int T, int NG, int WS>
 __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int tid, const Recs<NG>& rc, Raw<NG, WS>& raw) {
     const DevFrame& f = a.f;
@@ -383,6 +427,12 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     const int lgW4 = (int)(it.geo & 7u), lgGPB = (int)((it.geo >> 4) & 15u);
     const float* wtab = ((it.geo >> 15) & 1u) ? f.weights_t : f.weights;  // TransformType.flip() for METHOD_DCT: tall or square
     const float* wt[3] = {wtab + it.wo[0], wtab + it.wo[1], wtab + it.wo[2]};
+    const __attribute__((address_space(1))) int32_t* cp[3] = {sgpr_ptr(f.coeff[0]), sgpr_ptr(f.coeff[1]), sgpr_ptr(f.coeff[2])};
+    const auto* kxt = sgpr_ptr(f.kx_tab);
+    const auto* kbt = sgpr_ptr(f.kb_tab);
+    const __attribute__((address_space(1))) float* lfp[3] = {sgpr_ptr(a.llf_in_item ? f.lf[0] : f.llf[0]), sgpr_ptr(a.llf_in_item ? f.lf[1] : f.llf[1]),
+                                                            sgpr_ptr(a.llf_in_item ? f.lf[2] : f.llf[2])};
+    const int cells_w = f.width >> 3, tw = f.tw, bw = f.bw;
 #pragma unroll
     for (int j = 0; j < NG; j++) {
         const int g = tid + T * j;
@@ -400,24 +450,17 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             const uint32_t cfl_zero = (uint32_t)rc.gz[j];
             raw.hfm[j] = (float)rc.gw[j];
             const int py = cy * 8 + n, px = cx * 8 + x4;
-            const int64_t off = coeff_off(f.width, py, px);  // cell-tiled int32 planes
-            if (a.coeff16[0]) {  // (uniform) 8 bytes per group and channel, widened here; the staged int16 planes are raster
+            // cell-tiled int32 planes (coeff_off): cell (py >> 3, px >> 3), 64 samples each
+            const int64_t off = (((int64_t)(py >> 3) * cells_w + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const v2i pk = *reinterpret_cast<const v2i*>(a.coeff16[c] + (int64_t)py * f.width + px);
-                    raw.q[j][c] = v4i{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const v4i*>(f.coeff[c] + off);
-            }
+            for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const __attribute__((address_space(1))) v4i*>(cp[c] + off);
             // chromaFromLuma factors of the tile this group lies in (4 consecutive x from a multiple of 4 never cross a
             // 64-px boundary), honouring the reference's per-group cache order (DevBlock::cfl_zero)
             const int ty = py >> 6, tx = px >> 6;
             const int bit = (ty - ((cy * 8) >> 6)) * 5 + (tx - ((cx * 8) >> 6));
             if (!((cfl_zero >> bit) & 1u)) {
-                raw.kx[j] = f.kx_tab[ty * f.tw + tx];
-                raw.kb[j] = f.kb_tab[ty * f.tw + tx];
+                raw.kx[j] = kxt[ty * tw + tx];
+                raw.kb[j] = kbt[ty * tw + tx];
             }
             raw.ok |= 1u << j;
         }
@@ -431,7 +474,18 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
         const int rr = tid - ((bl * 3) << lgA), c = rr >> lgA, k = rr & ((1 << lgA) - 1);
         const int ky = k >> lgDSW, kx = k & ((1 << lgDSW) - 1);
         const int cy = (int)((uint32_t)rc.lx & 0xffffu), cx = (int)((uint32_t)rc.lx >> 16);
-        raw.llf = (a.llf_in_item ? f.lf[c] : f.llf[c])[(int64_t)(cy + ky) * f.bw + cx + kx];
+        const auto* lp = c == 0 ? lfp[0] : c == 1 ? lfp[1] : lfp[2];  // (selects, not a per-lane load of the pointer)
+        raw.llf = lp[(int64_t)(cy + ky) * bw + cx + kx];
+    }
+    // the block of the row this lane will store in the row pass (lane -> row ridx = tid % (NB * H), block ridx / H): r1-r3 loaded
+    // the record at the start of the passes, and the compiler waited for it -- vmcnt(0), i.e. for this whole prefetch -- before
+    // the column pass had begun. It travels with the prefetch now and is covered by the same wait in front of the stores.
+    {
+        constexpr int P = T * NG * 4;
+        const int lgW = lgW4 + 2, lgH = lgGPB - lgW4;
+        const int rb = (tid & ((P >> lgW) - 1)) >> lgH;
+        raw.rowx = 0;
+        if (it.type >= 0 && rb < it.nb) raw.rowx = sgpr_ptr(reinterpret_cast<const int*>(a.blocks))[4 * (it.first + rb)];
     }
 }
 
@@ -536,7 +590,7 @@ struct Body {
 
     // ---- B + C. column pass (in place), row pass -> frame planes
     template <typename PreStore>
-    static __device__ __forceinline__ void passes(const Wg3Args& a, const Item& it, int tid, float* __restrict__ img, int it_no,
+    static __device__ __forceinline__ void passes(const Wg3Args& a, const Item& it, int tid, float* __restrict__ img, int it_no, int rowx,
                                                   PreStore pre_store) {
         (void)it_no;
         const DevFrame& f = a.f;
@@ -546,9 +600,6 @@ struct Body {
         const int cb = cidx / W, cxx = cidx % W;
         const int ridx = tid % (C::NB * H), kc_row = __builtin_amdgcn_readfirstlane(tid / (C::NB * H));
         const int rb = ridx / H, ry = ridx % H;
-        // block of this lane's row (row pass output address): requested now, needed two barriers later
-        v4i rrec = v4i{0, 0, 0, 0};
-        if (rb < it.nb) rrec = ((cv4ip)a.blocks)[it.first + rb];
         {
             constexpr int KC = C::KC_COL;
             Acc3<KC> acc;
@@ -589,7 +640,7 @@ struct Body {
             if (rb < it.nb) {
 #endif
                 float* o3[3] = {a.o0, a.o1, a.o2};
-                const int cy = (int)((uint32_t)rrec.x & 0xffffu), cx = (int)((uint32_t)rrec.x >> 16);
+                const int cy = (int)((uint32_t)rowx & 0xffffu), cx = (int)((uint32_t)rowx >> 16);  // (prefetched with the item: Raw::rowx)
                 const int64_t off = (int64_t)(cy * 8 + ry) * f.width + cx * 8;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
@@ -636,25 +687,25 @@ __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int
     }
 }
 template <bool BIG, typename PreStore>
-__device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int tid, float* img, int it_no, PreStore pre_store) {
+__device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int tid, float* img, int it_no, int rowx, PreStore pre_store) {
     if constexpr (BIG) {
         switch (it.type) {
-        case 18: Body<64, 64, 18>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 19: Body<64, 32, 19>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 20: Body<32, 64, 20>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 18: Body<64, 64, 18>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 19: Body<64, 32, 19>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 20: Body<32, 64, 20>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         default: __builtin_unreachable();  // item_of hands out the types of this class only
         }
     } else {
         switch (it.type) {
-        case 0: Body<8, 8, 0>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 4: Body<16, 16, 4>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 5: Body<32, 32, 5>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 6: Body<16, 8, 6>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 7: Body<8, 16, 7>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 8: Body<32, 8, 8>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no, pre_store); break;
-        case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no, pre_store); break;
+        case 0: Body<8, 8, 0>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 4: Body<16, 16, 4>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 5: Body<32, 32, 5>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 6: Body<16, 8, 6>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 7: Body<8, 16, 7>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 8: Body<32, 8, 8>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+        case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         default: __builtin_unreachable();  // item_of hands out the types of this class only
         }
     }
@@ -724,7 +775,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         }
 #pragma unroll
         for (int j = 0; j < WS; j++) asm volatile("" ::"v"(raw.w[j][0]), "v"(raw.w[j][1]), "v"(raw.w[j][2]));
-        asm volatile("" ::"v"(raw.llf), "v"(rc.lx));
+        asm volatile("" ::"v"(raw.llf), "v"(rc.lx), "v"(raw.rowx));
     };
     loads_landed();
     if (tid0 < 192) lf_patch[tid0] = raw.llf;
@@ -744,6 +795,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         do_dequant<BIG>(a, cur, tid, raw, img, qtab);  // the loads were issued one item ago
+        const int rowx = raw.rowx;                     // (the prefetch below overwrites raw)
         STAMP3(1);
         lds_barrier();
         STAMP3(2);
@@ -754,7 +806,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         const Item nn = item_of<P>(a, gi + G);
         load_recs<T, NG>(a, nn, tid, rc);
         STAMP3(3);
-        do_passes<BIG>(a, cur, tid, img, it_no, landed_and_published);
+        do_passes<BIG>(a, cur, tid, img, it_no, rowx, landed_and_published);
         if (nxt.type < 0) break;
         cur = nxt;
         nxt = nn;
@@ -764,6 +816,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         it_no++;
     }
     STAMP3_LIFE(1, __builtin_amdgcn_s_memtime() | ((unsigned long long)(it_no + 1) << 56));
+    STAMP3_FLUSH();
 }
 
 template <bool BIG>
@@ -887,7 +940,6 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.img_floats = 0;
     a.items = nullptr;
     a.llf_in_item = wg3_llf_in_item() ? 1 : 0;
-    a.coeff16[0] = a.coeff16[1] = a.coeff16[2] = nullptr;
     static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
     for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;

@@ -43,41 +43,3 @@ def test_switched_kernel_is_bit_exact(switch):
     env[name] = val or "1"
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RESULT 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-SCRIPT_I16 = r"""
-import sys
-sys.path.insert(0, %r)
-import numpy as np
-from jxlatte_amd import _lib, abi, host, synth
-from oracle import pyoracle as orc
-ctx = _lib.Context(0)
-bad = 0
-for mix, seed, size in (("default", 2, (512, 256)), ("all", 3, (512, 512)), ("dct8", 4, (264, 136)), ("default", 7, (1000, 520))):
-    frame = synth.make_vardct_frame(size[0], size[1], seed=seed, mix=mix)
-    fr = host.Frame(ctx, frame["params"], frame["weights"], frame["woffs"])
-    for g in frame["lfgroups"]:
-        fr.setLFGroup(g)
-    mp = fr.mapCoeffsI16()
-    for ch in range(3):
-        assert np.abs(frame["coeff"][ch]).max() < 32768
-        np.copyto(mp[ch], np.ascontiguousarray(frame["coeff"][ch], np.int16))
-    fr.commitCoeffsI16()
-    got = fr.decodeFrame()
-    exp = orc.vardct_frame(frame, stages=frame["params"].stages)
-    n = int((got.view(np.uint32) != exp.view(np.uint32)).sum())
-    print(mix, size, "mismatch", n)
-    bad += n
-print("RESULT", bad)
-sys.exit(1 if bad else 0)
-""" % ROOT
-
-
-def test_int16_resident_coefficients_are_bit_exact():
-    """JXL_WG3_I16=1 (kept as an experiment): the k_idct_wg3 prefetch reads the committed int16 wire-format
-    planes instead of the widened int32 planes; same bits as the oracle"""
-    env = dict(os.environ)
-    env["JXL_WG3_I16"] = "1"
-    env["JXL_COMMIT_ZEROCOPY"] = "0"  # the experiment reads the staged int16 planes on the device
-    r = subprocess.run([sys.executable, "-c", SCRIPT_I16], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "RESULT 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
