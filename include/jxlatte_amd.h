@@ -232,8 +232,8 @@ jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* ctx);
 jxl_status jxl_vardct_map_coeffs_i16_ex(jxl_ctx* ctx, int16_t* planes[3], int32_t strides[3], int32_t flags);
 jxl_status jxl_vardct_commit_coeffs_i16_groups(jxl_ctx* ctx, const uint8_t* group_written, int32_t n_groups);
 /* Page-locked host memory for the buffers that cross the bus (coefficient planes in, pixel planes out; a JNI caller wraps it
- * with NewDirectByteBuffer). put_group / put_group_i16 / read_output recognise such pointers: the copy is a direct DMA at
- * bus speed instead of the runtime's staged copy out of pageable memory, and put_group returns without waiting for it
+ * with NewDirectByteBuffer). put_group / put_group_i16 / read_output recognise such pointers: the device reads / writes them
+ * in place at bus speed instead of through a staged copy out of pageable memory, and put_group returns without waiting
  * (the buffer must stay untouched until jxl_vardct_run or jxl_ctx_synchronize). NULL on failure. */
 void* jxl_host_alloc(size_t bytes);
 void jxl_host_free(void* p);

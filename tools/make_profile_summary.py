@@ -116,7 +116,7 @@ L += ["", "## 3. the dominant kernel", "",
       % (rk, dur[rk], s["SQ_INSTS_VALU"], s["SQ_INSTS_VALU"] * 64 / (3840 * 2160)),
       "At the measured peak issue rate (%.1f cycles per wave-instruction and SIMD, tools/ubench/pk_rate.hip; packed f32 issues at half that rate,"
       % ISSUE_CYCLES,
-      "so it buys nothing) that is %.1f us of VALU time over 1024 SIMDs at 2.4 GHz = %.0f %% of the launch. LDS: %.3g active cycles (%.1f us per CU),"
+      "so it buys this kernel nothing) that is %.1f us of VALU time over 1024 SIMDs at 2.4 GHz = %.0f %% of the launch. LDS: %.3g active cycles (%.1f us per CU),"
       % (valu_us, 100 * valu_us / dur[rk], lds_s.get("SQ_LDS_IDX_ACTIVE", 0), lds_s.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / 2.4e3),
       "%.3g of them bank conflicts. HBM bytes per launch (corrected): %.1f MB vs %.1f MB algorithmic (%.1f us at 8 TB/s)."
       % (lds_s.get("SQ_LDS_BANK_CONFLICT", 0), traffic["hbm_bytes_per_launch"] / 1e6, (3840 * 2160 * 24 + 129600 * 8) / 1e6,
