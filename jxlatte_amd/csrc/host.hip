@@ -655,9 +655,9 @@ jxl_status finalize_tables(jxl_ctx* c) {
         for (int k = 0; k < 2; k++) {
             c->wg3_item_count[k] = 0;
             for (const auto& tl : c->type_launches) {
-                if (tl.cls != 2 + k || !spatial) continue;
-                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, wg3_tab[k], wg3_grid_cap(k == 1));
-                c->wg3_item_count[k] = (int)(wg3_tab[k].size() / 4);
+                if (tl.cls != 2 + k) continue;
+                wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, c->woffs, spatial, wg3_tab[k], wg3_grid_cap(k == 1));
+                c->wg3_item_count[k] = (int)(wg3_tab[k].size() / 8);
             }
             c->wave_item_count[k] = 0;
             if (c->wave_segs.empty()) continue;
@@ -1749,7 +1749,8 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 if (tl.cls >= 2) {
                     wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
                     if (wn[tl.cls - 2] < 0) return fail(c, JXL_ERR_STATE, "IDCT launch: too many segments");
-                    if (c->wg3_item_count[tl.cls - 2] == wn[tl.cls - 2]) wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
+                    if (c->wg3_item_count[tl.cls - 2] != wn[tl.cls - 2]) return fail(c, JXL_ERR_STATE, "IDCT launch: item list out of date");
+                    wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
                     all.insert(all.end(), tl.segs.begin(), tl.segs.end());
                 }
             if (!all.empty()) {
@@ -2120,7 +2121,10 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
                 const int items = build_wg3_args(f, c->blocks.as<DevBlock>(), segs.data(), (int)segs.size(), cls == 10 ? 2 : cls - 11, A, a);
                 if (items < 0) return fail(c0, JXL_ERR_STATE, "IDCT launch: too many segments");
                 if (items <= 0) continue;
-                if (cls != 10 && c->wg3_item_count[cls - 11] == items) a.items = c->wg3_items[cls - 11].as<int>();
+                if (cls != 10) {
+                    if (c->wg3_item_count[cls - 11] != items) return fail(c0, JXL_ERR_STATE, "IDCT launch: item list out of date");
+                    a.items = c->wg3_items[cls - 11].as<int>();
+                }
                 if (cls == 10) {
                     const int64_t nl = a.llf_in_item ? 0 : wg3_llf_count(a);  // the items do finalizeLLF themselves: no launch
                     if (nl <= 0) continue;

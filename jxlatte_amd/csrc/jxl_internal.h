@@ -119,13 +119,14 @@ struct Wg3Args {
     int n_seg, total_items;
     int img_floats;  // floats of the largest three-channel LDS image among the segments' types (the tables follow it)
     int llf_in_item;  // 1: the items transform their blocks' LF patches themselves (finalizeLLF); 0: k_llf_wg3 ran before (llf planes)
-    // optional explicit item list (16-byte records {type, first_block, n_blocks, 0}, total_items of them) in the order the
-    // workgroups should take them -- spatial, see wg3_item_table; nullptr: the items follow from the segments, type by type
+    // the item list: 32-byte records {type, first_block, n_blocks, geometry word (wg3_geo), weight offsets of the three channels, 0},
+    // total_items of them, in the order the workgroups take them (wg3_item_table: spatial, dealt to the XCDs, cost-balanced)
     const int* items;
     Wg3Seg seg[kMaxSeg];
 };
 // the item list of one class's segments in spatial order, dealt to the XCDs in runs (host side)
-void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out, int grid);
+void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int which, const int32_t* woffs, bool spatial,
+                    std::vector<int>& out, int grid);
 int wg3_grid_cap(bool big);  // workgroups of a single-frame launch (JXL_WG3_GRID / JXL_WG3_GRID_BIG)
 bool wg3_handles(int type);
 bool wg3_big(int type);  // the 64-point family: its own launch (register / LDS class)

@@ -313,7 +313,7 @@ struct Item {
     int first;     // first block record
     int nb;        // blocks of the item
     uint32_t geo;  // run-time geometry of the type for the type-generic prefetch (wg3_geo)
-    int wo[3];     // offsets of the type's three weight matrices (DevFrame::woffs of its parameter index)
+    int gi;        // its position in the launch's item list (the prefetch reads the weight offsets from the record itself)
 };
 
 // geometry word of a type: bits 0-2 log2(W / 4), 4-7 log2(H * W / 4) (4-sample groups per block), 8-10 log2 of the LLF
@@ -327,35 +327,19 @@ __host__ __device__ inline uint32_t wg3_geo(int type) {
            (H >= W ? 1u << 15 : 0u) | (uint32_t)JXL_TT[type].param_index << 16;
 }
 
+// Item gi of the launch: ONE 32-byte record {type, first block, blocks, geometry word, weight offsets of the three channels, 0}
+// of the list finalize_tables built (wg3_item_table) -- one s_load_dwordx8, nothing looked up behind it (r1-r3: a 16-byte
+// record, the weight offsets through DevFrame::woffs behind it, and a walk over the launch's segments when no list was given).
 template <int P>
 __device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
-    Item it{-1, 0, 0, 0u, {0, 0, 0}};
+    Item it{-1, 0, 0, 0u, 0};
     if (gi >= a.total_items) return it;
-    if (a.items) {  // explicit list (uniform index: scalar loads)
-        const auto* w = (const __attribute__((address_space(4))) int*)a.items + 4 * gi;
-        it.type = w[0];
-        it.first = w[1];
-        it.nb = w[2];
-        it.geo = (uint32_t)w[3];
-        const int pi3 = (int)((it.geo >> 16) & 0xffu) * 3;
-        it.wo[0] = a.f.woffs[pi3];
-        it.wo[1] = a.f.woffs[pi3 + 1];
-        it.wo[2] = a.f.woffs[pi3 + 2];
-        return it;
-    }
-    int k = 0;
-    while (k + 1 < a.n_seg && gi >= a.seg[k + 1].item_base) k++;
-    const Wg3Seg sg = a.seg[k];
-    const int li = gi - sg.item_base;
-    const int NB = P / ((int)JXL_TT[sg.type].ph * (int)JXL_TT[sg.type].pw);
-    it.type = sg.type;
-    it.first = sg.first_block + li * NB;
-    it.nb = min(NB, sg.n_blocks - li * NB);
-    it.geo = wg3_geo(sg.type);
-    const int pi3 = (int)JXL_TT[sg.type].param_index * 3;
-    it.wo[0] = a.f.woffs[pi3];
-    it.wo[1] = a.f.woffs[pi3 + 1];
-    it.wo[2] = a.f.woffs[pi3 + 2];
+    const auto* w = (const __attribute__((address_space(4))) int*)a.items + 8 * gi;
+    it.type = w[0];
+    it.first = w[1];
+    it.nb = w[2];
+    it.geo = (uint32_t)w[3];
+    it.gi = gi;
     return it;
 }
 
@@ -426,7 +410,9 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     raw.llf = 0.0f;
     const int lgW4 = (int)(it.geo & 7u), lgGPB = (int)((it.geo >> 4) & 15u);
     const float* wtab = ((it.geo >> 15) & 1u) ? f.weights_t : f.weights;  // TransformType.flip() for METHOD_DCT: tall or square
-    const float* wt[3] = {wtab + it.wo[0], wtab + it.wo[1], wtab + it.wo[2]};
+    // (words 4-6 of the item's record: read here, where they are used, instead of carried in SGPRs through two items)
+    const auto* irec = (const __attribute__((address_space(4))) int*)a.items + 8 * it.gi;
+    const float* wt[3] = {wtab + irec[4], wtab + irec[5], wtab + irec[6]};
     const __attribute__((address_space(1))) int32_t* cp[3] = {sgpr_ptr(f.coeff[0]), sgpr_ptr(f.coeff[1]), sgpr_ptr(f.coeff[2])};
     const auto* kxt = sgpr_ptr(f.kx_tab);
     const auto* kbt = sgpr_ptr(f.kb_tab);
@@ -985,7 +971,8 @@ static float wg3_item_cost(int type) {  // us per 4K frame tiled with the type (
     }
 }
 
-void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, int n_seg, int which, std::vector<int>& out, int grid) {
+void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, int n_seg, int which, const int32_t* woffs, bool spatial,
+                    std::vector<int>& out, int grid) {
     struct Rec { uint32_t key; int type, first, nb; };
     std::vector<Rec> recs;
     static const int rsh = getenv("JXL_WG3_REGION_SHIFT") ? std::min(12, std::max(0, atoi(getenv("JXL_WG3_REGION_SHIFT")))) : 5;
@@ -998,6 +985,16 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
             recs.push_back(Rec{(uint32_t)((b0.cy >> rsh) * grs + (b0.cx >> rsh)), segs[i].type, segs[i].first_block + o, std::min(nb, segs[i].n_blocks - o)});
         }
     }
+    auto emit = [&](const Rec& r) {
+        const int pi3 = (int)JXL_TT[r.type].param_index * 3;
+        const int rec[8] = {r.type, r.first, r.nb, (int)wg3_geo(r.type), woffs[pi3], woffs[pi3 + 1], woffs[pi3 + 2], 0};
+        out.insert(out.end(), rec, rec + 8);
+    };
+    if (!spatial) {  // JXL_WG3_SPATIAL=0: the segments' own order, type after type
+        out.clear();
+        for (const Rec& r : recs) emit(r);
+        return;
+    }
     std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
     static const int run = getenv("JXL_WG3_RUN") ? std::max(1, atoi(getenv("JXL_WG3_RUN"))) : 24;
     std::vector<const Rec*> q[8];
@@ -1005,7 +1002,7 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
     size_t longest = 0;
     for (auto& v : q) longest = std::max(longest, v.size());
     out.clear();
-    out.reserve(recs.size() * 4);
+    out.reserve(recs.size() * 8);
     std::vector<const Rec*> lst;
     lst.reserve(recs.size());
     for (size_t i = 0; i < longest; i++)
@@ -1038,9 +1035,7 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
             }
         }
     }
-    for (const Rec* r : lst) {
-        out.push_back(r->type); out.push_back(r->first); out.push_back(r->nb); out.push_back((int)wg3_geo(r->type));
-    }
+    for (const Rec* r : lst) emit(*r);
 }
 
 // LLF coefficients of the class's blocks into the llf planes (must precede launch_idct_wg3 on the same stream)
