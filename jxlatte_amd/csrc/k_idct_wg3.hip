@@ -69,8 +69,9 @@ typedef const __attribute__((address_space(4))) float* cfloatp;
 typedef const __attribute__((address_space(4))) v4i* cv4ip;
 
 __constant__ float kLlfScale3[32] = JXL_LLF_SCALE_INIT;
-// LDS behind the block images: [3][64] dequantisation table | [104] finalizeLLF tables | [192] LF patches | [3][256] scaleFactor[c] / m
-constexpr int kWg3AuxFloats = 3 * 64 + 104 + 192;
+// LDS behind the block images: [3][128] dequantisation table | [104] finalizeLLF tables | [192] LF patches | [3][256] scaleFactor[c] / m
+constexpr int kWg3QTab = 3 * 128;  // dequantisation table: [3][128], entry q + 64 for q = -64 .. 63
+constexpr int kWg3AuxFloats = kWg3QTab + 104 + 192;
 constexpr int kWg3SfEntries = 256;
 
 // Diagnostic build only (-DJXL_STAMPS): lane 0 of every workgroup records s_memtime at the phase boundaries of its first
@@ -424,13 +425,16 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
         const int g = tid + T * j;
         const int b = g >> lgGPB, r = g & ((1 << lgGPB) - 1);
         const int n = r >> lgW4, x4 = (r & ((1 << lgW4) - 1)) << 2;
+        // (256-thread class: raw.q / raw.hfm of a group outside the item keep whatever they held -- dequant() skips such groups,
+        // Raw::ok -- which saves 26 v_mov per item; in the 512-thread class the re-definition ends their live ranges, without it
+        // the kernel spills 12 registers instead of 3)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            raw.q[j][c] = v4i{0, 0, 0, 0};
+            if (WS > 1) raw.q[j][c] = v4i{0, 0, 0, 0};
             if (WS > 1 || j == 0) raw.w[WS == 1 ? 0 : j][c] = *reinterpret_cast<const v4f*>(wt[c] + r * 4);  // row-major [n][x]: n * W + x4 = 4 r
         }
         raw.kx[j] = raw.kb[j] = 0.0f;
-        raw.hfm[j] = 1.0f;
+        if (WS > 1) raw.hfm[j] = 1.0f;
         if (it.type >= 0 && b < it.nb) {
             const int cy = (int)((uint32_t)rc.gx[j] & 0xffffu), cx = (int)((uint32_t)rc.gx[j] >> 16);  // DevBlock
             const uint32_t cfl_zero = (uint32_t)rc.gz[j];
@@ -514,30 +518,28 @@ struct Body {
             // them as one <12 x float> and keep the whole prefetch state in scratch memory)
 #define QV(c, i) (raw.q[j][c][i])
 #define WV(c, i) (raw.w[C::WS == 1 ? 0 : j][c][i])
-            // HFCoefficients.dequantizeHFCoefficients inner expression (:309-315) through the tables: tab[a] = 0, quantBias,
-            // (float)a - qbn / (float)a for a = 0, 1, 2..63, applied with the sign of q ((float)q - qbn / (float)q ==
-            // -((float)|q| - qbn / (float)|q|) for q < 0 exactly: IEEE negation commutes with round-to-nearest division and
-            // subtraction). One branch per group for the rare |q| >= 64 instead of one per sample.
+            // HFCoefficients.dequantizeHFCoefficients inner expression (:309-315) through a table indexed by the SIGNED value
+            // (r4): tab[q + 64] = 0, +-quantBias, (float)q - qbn / (float)q for q = -64 .. 63 -- the reference's own expression
+            // per entry, so neither |q| nor the sign has to be formed per sample (r3: tab[|q|] and the sign by XOR: two more
+            // instructions per sample, 48 per lane and item). One branch per group for the rare q outside the table instead
+            // of one per sample.
             float dq[3][4];
-            int big = 0;
+            uint32_t big = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int qv = QV(c, i);
-                    const int aq = qv < 0 ? -qv : qv;
-                    big |= aq;
-                    const float m = qtab[c * 64 + (aq & 63)];
-                    dq[c][i] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, m) ^ ((uint32_t)qv & 0x80000000u));
+                    const uint32_t t = (uint32_t)QV(c, i) + 64u;
+                    big |= t;
+                    dq[c][i] = qtab[c * 128 + (t & 127u)];
                 }
-            if ((uint32_t)big >= 64u) {
+            if (big >= 128u) {
 #pragma unroll
                 for (int c = 0; c < 3; c++)
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int qv = QV(c, i);
-                        const int aq = qv < 0 ? -qv : qv;
-                        if (aq >= 64) dq[c][i] = (float)qv - qbn / (float)qv;
+                        if ((uint32_t)qv + 64u >= 128u) dq[c][i] = (float)qv - qbn / (float)qv;
                     }
             }
             float* d0 = img + (0 * C::NB + b) * C::IMG + n * C::LD + x4;
@@ -566,7 +568,7 @@ struct Body {
                 float v = raw.llf;
                 if (C::DSH * C::DSW > 1 && a.llf_in_item) {
                     // forwardDCT2D of the block's LF patch, which the item's lanes published in lf_patch[] one barrier ago
-                    const float* aux = qtab + 192;  // [70] cosine LUT of 2, 4, 8 points | [2] | [32] LLF scale | [192] LF patches
+                    const float* aux = qtab + kWg3QTab;  // [70] cosine LUT of 2, 4, 8 points | [2] | [32] LLF scale | [192] LF patches
                     v = llf_coeff3<C::DSH, C::DSW>(aux, aux + 104 + b * C::PER_B + c * (C::DSH * C::DSW), C::DSW, k / C::DSW, k % C::DSW, aux + 72);
                 }
                 img[(c * C::NB + b) * C::IMG + (k / C::DSW) * C::LD + (k % C::DSW)] = v;
@@ -726,14 +728,14 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     if (cur.type < 0) return;
     STAMP3_LIFE(0, __builtin_amdgcn_s_memtime());
     float* img = lds;
-    float* qtab = lds + a.img_floats;  // [3][64]: 0, quantBias[c], (float)a - qbn / (float)a
-    if (tid0 < 192) {
-        const int c = tid0 >> 6, aq = tid0 & 63;
-        qtab[tid0] = aq == 0 ? 0.0f : aq == 1 ? a.f.quant_bias[c] : (float)aq - a.f.quant_bias_numerator / (float)aq;
+    float* qtab = lds + a.img_floats;  // [3][128]: entry q + 64 = 0, +-quantBias[c], (float)q - qbn / (float)q (HFCoefficients.java:309-315)
+    for (int i = tid0; i < kWg3QTab; i += T) {
+        const int c = i >> 7, q = (i & 127) - 64;
+        qtab[i] = q == 0 ? 0.0f : q == 1 ? a.f.quant_bias[c] : q == -1 ? -a.f.quant_bias[c] : (float)q - a.f.quant_bias_numerator / (float)q;
     }
     // finalizeLLF inside the item: the cosine tables of 2, 4 and 8 points (the first 70 floats of the LUT), the LLF scale
     // table and one LF sample per LLF coefficient of the coming item (lf_patch, written when the item's prefetch has landed)
-    float* aux = qtab + 192;
+    float* aux = qtab + kWg3QTab;
     float* lf_patch = aux + 104;
     if (tid0 < 70) aux[tid0] = a.f.lut[tid0];
     else if (tid0 >= 72 && tid0 < 104) aux[tid0] = kLlfScale3[tid0 - 72];
@@ -741,7 +743,7 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         const int c = i / kWg3SfEntries, m = i % kWg3SfEntries;
         qtab[kWg3AuxFloats + i] = a.f.scale_factor[c] / (float)(m > 0 ? m : 1);
     }
-    Raw<NG, WS> raw;
+    Raw<NG, WS> raw{};  // (zeroed once: the prefetch leaves the groups outside an item alone)
     Recs<NG> rc;
     load_recs<T, NG>(a, cur, tid0, rc);
     prefetch<T, NG, WS>(a, cur, tid0, rc, raw);
