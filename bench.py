@@ -298,11 +298,16 @@ def main():
     ms_all_b, ms_idct_b, ms_rest_b = stage_ms()  # inside the timed region (other frames' kernels overlap)
     launches = frames[0].lastLaunchCount()
     # the same events with frame 0 alone on the device: the kernels' own durations (what rocprofv3 reports per launch)
+    # (r4: the runs are enqueued back to back -- the frame's launches are ordered on its streams, so each run still has the device
+    # to itself, but the chip holds its clock; with a host synchronisation between the runs it does not, and the figures of one
+    # box ranged over 104-129 us for the same kernels)
     torch.cuda.synchronize()
-    ctxs[0].call("jxl_vardct_enable_stage_timing", 1)
-    for _ in range(max(5, min(args.steps, 30))):
+    for _ in range(8):
         frames[0].run()
-        ctxs[0].synchronize()
+    ctxs[0].call("jxl_vardct_enable_stage_timing", 1)
+    for _ in range(32):
+        frames[0].run()
+    ctxs[0].synchronize()
     ms_all, ms_idct, ms_rest = stage_ms()
     ctxs[0].call("jxl_vardct_enable_stage_timing", 0)
 
@@ -397,7 +402,7 @@ def main():
     roofline = {
         "bound": "valu", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": "k_restore_fused (Gab, EPF x%d, XYB%s): HIP events around the launch, frame 0 alone on the device"
+        "kernel": "k_restore_fused (Gab, EPF x%d, XYB%s): HIP events around the launch, frame 0 alone on the device (mean of 32 runs enqueued back to back)"
                   % (epf_iters, ", PQ + u16" if args.workload == "vardct8k_pq" else ""),
         "kernel_ms": round(ms_rest, 4), "algorithmic_bytes_per_launch": int(rest_bytes),
         "kernel_ms_in_batch": round(ms_rest_b, 4),
