@@ -130,8 +130,14 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                             hc[py][j] = hc[py][j] + adiff<NW>(nb, u, u + 1, sc);
                         }
                 }
+#ifdef JXL_ABL_NO_NCHAIN  // timing experiment (wrong results): the chain towards the row above is not formed -- what fetching it from
+            // the lane above (its south chain) could save at most, before any exchange cost
+            constexpr int I0 = 1;
+#else
+            constexpr int I0 = 0;
+#endif
 #pragma unroll
-            for (int i = 0; i <= PH; i++)
+            for (int i = I0; i <= PH; i++)
 #pragma unroll
                 for (int px = 0; px < 4; px++) {
                     const int cy = i - 1 + R, cx = px + R;
@@ -150,7 +156,11 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
             for (int px = 0; px < 4; px++) {
                 dist[py * 4 + px][0] = hc[py][px];      // tap (0,-1)
                 dist[py * 4 + px][1] = hc[py][px + 1];  // tap (0,+1)
+#ifdef JXL_ABL_NO_NCHAIN
+                dist[py * 4 + px][2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((int)threadIdx.x - 8) << 2, __builtin_bit_cast(int, vc[py + 1][px])));
+#else
                 dist[py * 4 + px][2] = vc[py][px];      // tap (-1,0)
+#endif
                 dist[py * 4 + px][3] = vc[py + 1][px];  // tap (+1,0)
             }
     } else {
