@@ -643,9 +643,15 @@ jxl_status finalize_tables(jxl_ctx* c) {
     c->large_count = (int)c->h_blocks.size() - c->large_first;
     c->llf_first = c->large_first;  // only the 128/256-edge blocks take their LLF from the llf planes (k_llf)
     c->llf_count = c->large_count;
-    for (int ch = 0; ch < 3 && c->sub; ch++) {
-        if (!c->hfm_sub[ch].ensure(4 * std::max<size_t>(1, h_hfm_sub[ch].size()))) return fail(c, JXL_ERR_OOM, "device allocation failed");
-        HIP_TRY(c, hipMemcpy(c->hfm_sub[ch].p, h_hfm_sub[ch].data(), 4 * h_hfm_sub[ch].size(), hipMemcpyHostToDevice));
+    if (c->sub) {
+        // kernels of the previous frame on this (non-blocking) stream may still read hfm_sub, and the source is pageable: wait for
+        // them, then copy on the same stream so that this frame's kernels are ordered behind the upload
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int ch = 0; ch < 3; ch++) {
+            if (!c->hfm_sub[ch].ensure(4 * std::max<size_t>(1, h_hfm_sub[ch].size()))) return fail(c, JXL_ERR_OOM, "device allocation failed");
+            HIP_TRY(c, hipMemcpyAsync(c->hfm_sub[ch].p, h_hfm_sub[ch].data(), 4 * h_hfm_sub[ch].size(), hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // h_hfm_sub is a local
     }
     const size_t nc = (size_t)c->bh * c->bw, nt = (size_t)c->th * c->tw;
     // item lists of the persistent / wave kernels
@@ -668,6 +674,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     mark("item tables");
     // chroma-from-luma factor per 64x64 tile, HFCoefficients.java:177-181: base + factor / colorFactor in float (one IEEE
     // division and one addition, the same two operations the per-sample device code used to perform)
+    tab_wait(c);  // first write into the staging buffer: a transfer queued by an earlier finalize of this frame has finished reading it
     {
         const volatile float cf = (float)c->p.color_factor;
         for (size_t i = 0; i < nt; i++) {
@@ -1361,6 +1368,7 @@ jxl_status jxl_vardct_set_lfgroup(jxl_ctx* c, const jxl_lfgroup_desc* g) {
     if (g->cells_h != eh || g->cells_w != ew)
         return fail(c, JXL_ERR_INVALID_ARGUMENT, "LF group (%d,%d) must be %dx%d cells, got %dx%d", g->lfg_y, g->lfg_x, eh, ew, g->cells_h, g->cells_w);
     const int gth = ceil_div(eh, 8), gtw = ceil_div(ew, 8);
+    tab_wait(c);  // prepare / run, then another LF group of the same frame: the queued transfer may still be reading the staging buffer
     for (int y = 0; y < eh; y++) {  // row copies into the frame-level grids (element-wise over four grids it was 1.1 ms per 4K frame)
         const size_t d = (size_t)(y0 + y) * c->bw + x0, s = (size_t)y * ew;
         memcpy(&c->h_hf_mul[d], g->hf_mul + s, sizeof(int32_t) * ew);

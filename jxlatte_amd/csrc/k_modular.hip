@@ -16,102 +16,10 @@
 //           (cache-resident planes). Large steps: k_inv_hsqueeze, a wave owns 64 rows and stages 16-pair chunks of
 //           avg/res through LDS so that global traffic stays row-contiguous while each lane walks its own row.
 #include "jxl_internal.h"
+#include "modular_tend.h"
 #include <cstdlib>
 
 namespace jxl {
-
-__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
-__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
-__device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
-
-// ModularChannel.tendency (ModularChannel.java:23-47), branch-free and split so that only the part that depends on
-// `a` (the previously OUTPUT sample: the serial dependency of the squeeze recurrence) sits on the critical path.
-// Everything derived from b and c alone is prepared ahead (TendPre). int32 wrap-around is kept everywhere, so the
-// result equals the reference also for samples near INT_MIN / INT_MAX.
-struct TendPre {
-    int32_t base;  // -3c - b
-    int32_t e;     // 2 (b - c)
-    int32_t twob;  // 2 b
-    int32_t b;
-    bool ge, le;   // b >= c, b <= c
-};
-
-__device__ __forceinline__ TendPre tend_pre(int32_t b, int32_t c) {
-    TendPre t;
-    t.base = wsub(wmul(-3, c), b);
-    t.e = wmul(2, wsub(b, c));
-    t.twob = wmul(2, b);
-    t.b = b;
-    t.ge = b >= c;
-    t.le = b <= c;
-    return t;
-}
-
-__device__ __forceinline__ int32_t tend_apply(int32_t a, const TendPre& t) {
-    const bool dec = t.ge && a >= t.b;           // if (a >= b && b >= c)
-    const bool inc = !dec && t.le && a <= t.b;   // else if (a <= b && b <= c)
-    const int32_t x = wadd(wadd(wmul(4, a), t.base), dec ? 6 : -6) / 12;
-    const int32_t d = wsub(wmul(2, a), t.twob);
-    // decreasing: if (x - (x&1) > d) x = d + 1; if (x + (x&1) > e) x = e;
-    int32_t xd = x;
-    xd = wsub(xd, xd & 1) > d ? wadd(d, 1) : xd;
-    xd = wadd(xd, xd & 1) > t.e ? t.e : xd;
-    // increasing: if (x + (x&1) < d) x = d - 1; if (x - (x&1) < e) x = e;
-    int32_t xi = x;
-    xi = wadd(xi, xi & 1) < d ? wsub(d, 1) : xi;
-    xi = wsub(xi, xi & 1) < t.e ? t.e : xi;
-    return dec ? xd : (inc ? xi : 0);
-}
-
-__device__ __forceinline__ int32_t tendency(int32_t a, int32_t b, int32_t c) { return tend_apply(a, tend_pre(b, c)); }
-
-// Short form of tend_apply for the serial chain. With d = 2(a-b) and e = 2(b-c) both even,
-//   "if (x - (x&1) > d) x = d + 1; if (x + (x&1) > e) x = e"  ==  x = min(min(x, d + 1), e)
-//   "if (x + (x&1) < d) x = d - 1; if (x - (x&1) < e) x = e"  ==  x = max(max(x, d - 1), e)
-// (rounding x to the even number below / above and comparing with an even bound is the same as comparing x with the bound
-// +-1; checked exhaustively on small ranges and on 10^7 random triples, tests/test_oracle_kats.py). The identities need
-// d +- 1 and x +- 1 not to wrap, which holds whenever |a-b| and |b-c| are below 2^29; `unsafe` collects the lanes where
-// that is not guaranteed and the caller redoes those steps with tend_apply. The two candidate quotients (+6 / -6) are
-// formed side by side, so no comparison sits in front of the division: ~13 dependent instructions instead of ~25.
-struct TendFast {
-    int32_t base_p6, base_m6;  // -3c - b + 6, -3c - b - 6
-    int32_t e, twob, b;
-    int32_t ge, le;            // all-ones / zero masks of b >= c, b <= c: the selection below is pure VALU bit logic,
-                               // no v_cmp -> SGPR -> s_and -> v_cndmask round trips on the serial chain
-    bool unsafe;
-};
-
-__device__ __forceinline__ TendFast tend_fast_pre(int32_t b, int32_t c) {
-    TendFast t;
-    const int32_t base = wsub(wmul(-3, c), b);
-    t.base_p6 = wadd(base, 6);
-    t.base_m6 = wsub(base, 6);
-    t.e = wmul(2, wsub(b, c));
-    t.twob = wmul(2, b);
-    t.b = b;
-    t.ge = b >= c ? -1 : 0;
-    t.le = b <= c ? -1 : 0;
-    // the range test looks at the WRAPPED difference: a true |b - c| of 2^32 - 2^29 or more wraps into the safe window
-    // (b = INT_MAX, c = INT_MIN gives -1), so a subtraction that overflowed is unsafe by itself
-    const int32_t bmc = wsub(b, c);
-    t.unsafe = ((uint32_t)bmc + 0x20000000u >= 0x40000000u) || (((b ^ c) & (b ^ bmc)) < 0);
-    return t;
-}
-
-__device__ __forceinline__ int32_t tend_fast_apply(int32_t a, const TendFast& t, bool& unsafe) {
-    const int32_t a4 = wmul(4, a);
-    const int32_t x6 = wadd(a4, t.base_p6) / 12, xm6 = wadd(a4, t.base_m6) / 12;
-    const int32_t d = wsub(wmul(2, a), t.twob);
-    const int32_t xd = min(min(x6, wadd(d, 1)), t.e);
-    const int32_t xi = max(max(xm6, wsub(d, 1)), t.e);
-    // inside the safe range a - b cannot wrap, so its sign is the comparison: lt = a < b, gt = a > b as masks
-    const int32_t amb = wsub(a, t.b);
-    const int32_t lt = amb >> 31, gt = wsub(t.b, a) >> 31;
-    const int32_t dec = t.ge & ~lt;         // b >= c && a >= b
-    const int32_t inc = t.le & ~gt & ~dec;  // else b <= c && a <= b
-    unsafe = unsafe || t.unsafe || ((uint32_t)amb + 0x20000000u >= 0x40000000u) || (((a ^ t.b) & (a ^ amb)) < 0);
-    return (xd & dec) | (xi & inc);
-}
 
 // One squeeze step is ONE launch over all of its channels: blockIdx.y selects the channel descriptor.
 // (SqueezeBatch is declared in jxl_internal.h.)
@@ -207,29 +115,22 @@ __global__ __launch_bounds__(64) void k_inv_squeeze_walk(const SqueezeBatch bt) 
         }
         if (y0 + RV <= ye) {  // full chunk: no guards on the serial chain, stores after it
             int32_t o1[RV], o2[RV];
-            TendFast tf[RV];
-#pragma unroll
-            for (int i = 0; i < RV; i++) tf[i] = tend_fast_pre(av[i], av[i + 1]);
             // the first pair of a column uses its own average as `left`; a warm-up start guesses the same
             const int32_t top0 = y0 > ys ? top : av[0];
             top = top0;
-            bool unsafe = false;
+            SqueezeRange rg;
+            rg.init(av[0]);
 #pragma unroll
-            for (int i = 0; i < RV; i++) {
-                const int32_t diff = wadd(rr[i], tend_fast_apply(top, tf[i], unsafe));
-                o1[i] = wadd(av[i], diff / 2);
-                o2[i] = wsub(o1[i], diff);
-                top = o2[i];
-            }
-            if (__builtin_expect(__any(unsafe), 0)) {  // operands near the int32 limits: exact long form for this chunk
-                top = top0;
+            for (int i = 0; i < RV; i++) rg.add(av[i + 1], rr[i]);
+            if (__builtin_expect(__all(rg.ok(top0)), 1)) {  // sign-normalised short form (modular_tend.h)
+                TendN tf[RV];
 #pragma unroll
-                for (int i = 0; i < RV; i++) {
-                    const int32_t diff = wadd(rr[i], tend_apply(top, tend_pre(av[i], av[i + 1])));
-                    o1[i] = wadd(av[i], diff / 2);
-                    o2[i] = wsub(o1[i], diff);
-                    top = o2[i];
-                }
+                for (int i = 0; i < RV; i++) tf[i] = tend_n_pre(av[i], av[i + 1], rr[i]);
+#pragma unroll
+                for (int i = 0; i < RV; i++) top = squeeze_pair_n(top, tf[i], o1[i], o2[i]);
+            } else {  // operands near the int32 limits: exact long form for this chunk
+#pragma unroll
+                for (int i = 0; i < RV; i++) top = squeeze_pair_exact(top, av[i], av[i + 1], rr[i], o1[i], o2[i]);
             }
             if (keep && HZ) {  // 16 consecutive outputs of the lane's row: four 16-byte stores
                 struct __attribute__((packed, aligned(4))) i4 { int32_t v[4]; };
@@ -383,28 +284,21 @@ __global__ __launch_bounds__(64) void k_inv_hsqueeze(const SqueezeBatch bt) {
                     for (int j = 0; j < U; j++) vr[j] = pr[i0 + j];
                     if (i0 + U == cols) va[U] = has_next ? a_next_chunk : va[U - 1];  // x + 1 < orig.width ? orig[x+1] : avg
                     int32_t o1[U], o2[U];
-                    TendFast tf[U];
-#pragma unroll
-                    for (int j = 0; j < U; j++) tf[j] = tend_fast_pre(va[j], va[j + 1]);
                     const int32_t left0 = (x0 + i0) > xs ? left : va[0];  // the first pair of a row uses its own average; a warm-up start guesses the same
                     left = left0;
-                    bool unsafe = false;
+                    SqueezeRange rg;
+                    rg.init(va[0]);
 #pragma unroll
-                    for (int j = 0; j < U; j++) {
-                        const int32_t diff = wadd(vr[j], tend_fast_apply(left, tf[j], unsafe));
-                        o1[j] = wadd(va[j], diff / 2);
-                        o2[j] = wsub(o1[j], diff);
-                        left = o2[j];
-                    }
-                    if (__builtin_expect(__any(unsafe), 0)) {  // operands near the int32 limits: exact long form
-                        left = left0;
+                    for (int j = 0; j < U; j++) rg.add(va[j + 1], vr[j]);
+                    if (__builtin_expect(__all(rg.ok(left0)), 1)) {  // sign-normalised short form (modular_tend.h)
+                        TendN tf[U];
 #pragma unroll
-                        for (int j = 0; j < U; j++) {
-                            const int32_t diff = wadd(vr[j], tend_apply(left, tend_pre(va[j], va[j + 1])));  // long form, built here: rare
-                            o1[j] = wadd(va[j], diff / 2);
-                            o2[j] = wsub(o1[j], diff);
-                            left = o2[j];
-                        }
+                        for (int j = 0; j < U; j++) tf[j] = tend_n_pre(va[j], va[j + 1], vr[j]);
+#pragma unroll
+                        for (int j = 0; j < U; j++) left = squeeze_pair_n(left, tf[j], o1[j], o2[j]);
+                    } else {  // operands near the int32 limits: exact long form
+#pragma unroll
+                        for (int j = 0; j < U; j++) left = squeeze_pair_exact(left, va[j], va[j + 1], vr[j], o1[j], o2[j]);
                     }
 #pragma unroll
                     for (int j = 0; j < U; j++) {

@@ -366,6 +366,85 @@ def test_cosine_lut_is_exactly_mirror_symmetric(orc):
         assert not (lut == 0).any()  # no signed-zero ambiguity
 
 
+def test_tendency_normalised_form(orc):
+    """the r5 device form of ModularChannel.tendency (csrc/modular_tend.h: tend_n_pre / squeeze_pair_n), restated
+    instruction by instruction on wrapped int32 / uint32 values: fold onto the decreasing branch with m = (b < c) ? -1 : 0,
+    unsigned multiply-high division by 12, min3 / max instead of the parity clamps and the branch selects. Must equal the
+    reference on the whole guarded range (|avg|, |next| < 2^23, |left| < 2^27: SqueezeRange in the same header); the guard
+    is not vacuous (outside it the form does differ)."""
+    def wrap(x):
+        return ((x + 2**31) % 2**32) - 2**31
+
+    def tdiv(n, d):
+        return np.where(n >= 0, n // d, -((-n) // d))
+
+    def ref(a, b, c):  # ModularChannel.java:23-47
+        dec = (a >= b) & (b >= c)
+        inc = (~dec) & (a <= b) & (b <= c)
+        d, e = wrap(2 * wrap(a - b)), wrap(2 * wrap(b - c))
+        x = tdiv(wrap(4 * a - 3 * c - b + 6), 12)
+        x = np.where(wrap(x - (x & 1)) > d, wrap(d + 1), x)
+        x = np.where(wrap(x + (x & 1)) > e, e, x)
+        y = tdiv(wrap(4 * a - 3 * c - b - 6), 12)
+        y = np.where(wrap(y + (y & 1)) < d, wrap(d - 1), y)
+        y = np.where(wrap(y - (y & 1)) < e, e, y)
+        return np.where(dec, x, np.where(inc, y, 0))
+
+    def dev(a, b, c):
+        bmc = wrap(b - c)
+        m = bmc >> 31
+        ab = wrap((bmc ^ m) - m)
+        bn = wrap((b ^ m) - m)
+        e2 = wrap(ab << 1)
+        base = wrap(wrap(wrap(wrap(ab << 1) + ab) + 6) - wrap(bn << 2))
+        k1 = wrap(1 - wrap(bn << 1))
+        an = wrap((a ^ m) - m)
+        n = wrap(wrap(an << 2) + base) % 2**32
+        x = wrap(((n * 0xAAAAAAAB) >> 32) >> 3)
+        d1 = wrap(wrap(an << 1) + k1)
+        r = np.maximum(np.minimum(np.minimum(x, d1), e2), 0)
+        return wrap((r ^ m) - m)
+    g = np.arange(-40, 41, dtype=np.int64)
+    A, B, C = np.meshgrid(g, g, g, indexing="ij")
+    assert np.array_equal(ref(A, B, C), dev(A, B, C))
+    rng = np.random.default_rng(5)
+    for sa, sb in ((2**27, 2**23), (2**10, 2**8), (2**20, 2**23), (2**23, 2**23)):
+        a = rng.integers(-sa + 1, sa, 1_000_000)
+        b = rng.integers(-sb + 1, sb, a.size)
+        c = rng.integers(-sb + 1, sb, a.size)
+        assert np.array_equal(ref(a, b, c), dev(a, b, c)), (sa, sb)
+        b2 = np.clip(a + rng.integers(-50, 51, a.size), -sb + 1, sb - 1)
+        c2 = np.clip(b2 + rng.integers(-50, 51, a.size), -sb + 1, sb - 1)
+        assert np.array_equal(ref(a, b2, c2), dev(a, b2, c2)), (sa, sb)
+    ea = np.array([2**27 - 1, -2**27 + 1, 2**23 - 1, -2**23 + 1, 0, 1, -1, 5, -6], np.int64)
+    eb = np.array([2**23 - 1, -2**23 + 1, 2**23 - 2, 0, 1, -1, 7, -9, 1000, -1000], np.int64)
+    A, B, C = np.meshgrid(ea, eb, eb, indexing="ij")
+    assert np.array_equal(ref(A, B, C), dev(A, B, C))
+    # outputs of a guarded chunk stay guarded: |second| <= 1.07 * 2^26 < 2^27 for inputs below 2^23 and any guarded left
+    a = rng.integers(-2**27 + 1, 2**27, 1_000_000)
+    b = rng.integers(-2**23 + 1, 2**23, a.size)
+    c = rng.integers(-2**23 + 1, 2**23, a.size)
+    r = rng.integers(-2**23 + 1, 2**23, a.size)
+    diff = r + ref(a, b, c)
+    first = b + tdiv(diff, 2)
+    assert np.abs(first - diff).max() < 2**27
+    # outside the guard the short form is wrong somewhere (so the guard is what makes it exact)
+    ext = np.array([2**31 - 1, -2**31, 2**30, -2**30, 2**29, 0, 1, -1], np.int64)
+    A, B, C = np.meshgrid(ext, ext, ext, indexing="ij")
+    assert (ref(A, B, C) != dev(A, B, C)).any()
+    # and the restated reference agrees with the oracle (two-pair rows: the second pair's left is the first pair's second output)
+    av = rng.integers(-1000, 1000, (2000, 2)).astype(np.int32)
+    rs = rng.integers(-50, 50, (2000, 2)).astype(np.int32)
+    out = orc.inv_hsqueeze(av, rs)
+    t0 = ref(av[:, 0].astype(np.int64), av[:, 0].astype(np.int64), av[:, 1].astype(np.int64))
+    d0 = rs[:, 0] + t0
+    f0 = av[:, 0] + tdiv(d0, 2)
+    t1 = ref(f0 - d0, av[:, 1].astype(np.int64), av[:, 1].astype(np.int64))
+    d1 = rs[:, 1] + t1
+    f1 = av[:, 1] + tdiv(d1, 2)
+    assert np.array_equal(out[:, 1], f0 - d0) and np.array_equal(out[:, 2], f1) and np.array_equal(out[:, 3], f1 - d1)
+
+
 def test_tendency_min_max_form(orc):
     """the device kernels' short form of ModularChannel.tendency (k_modular.hip, tend_fast_apply): min/max instead of the
     parity-and-compare clamps. Checked against the oracle's inverse squeeze through 1-pair rows (out[1] = avg + diff/2 - diff
