@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libjxlatte_amd.so")
-SOURCES = ["k_idct.hip", "k_idct_wg3.hip", "k_idct_wave.hip", "k_restore.hip", "k_restore_fused.hip", "k_restore_fused_gen.hip", "k_restore_fused_q.hip", "k_restore_stream.hip", "k_modular.hip", "k_lf.hip", "k_post.hip", "host.hip"]
+SOURCES = ["k_idct.hip", "k_idct_wg3.hip", "k_idct_wave.hip", "k_restore.hip", "k_restore_fused.hip", "k_restore_fused_gen.hip", "k_restore_fused_q.hip", "k_restore_stream.hip", "k_modular.hip", "k_modular_vh.hip", "k_lf.hip", "k_post.hip", "host.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

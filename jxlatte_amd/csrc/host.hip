@@ -53,7 +53,9 @@ struct DevBuf {
 };
 
 struct ModOp {
-    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy, 4 batched squeeze step (bt), 5 chain of small steps (chain_*)
+    int kind;  // 0 hsqueeze, 1 vsqueeze, 2 rct, 3 copy, 4 batched squeeze step (bt), 5 chain of small steps (chain_*),
+               // 6 a V step and the H step behind it in one launch (vh; r5, only in jxl_ctx::mod_ops_fused)
+    VHBatch vh;
     const SqueezeBatch* chain_dev = nullptr;
     int chain_steps = 0, chain_slots = 0;
     SqueezeBatch bt;
@@ -213,7 +215,8 @@ struct jxl_ctx {
 
     // ---- Modular state
     std::vector<DevBuf> mod_bufs;
-    std::vector<ModOp> mod_ops;
+    std::vector<ModOp> mod_ops;        // the plan, one launch per squeeze step (what a reported mismatch falls back to)
+    std::vector<ModOp> mod_ops_fused;  // the same plan with every (V, H) pair of steps as one launch (r5): what jxl_modular_run runs
     std::vector<ModChan> mod_out;
     // speculative verification of the segmented squeeze walks (jxl_modular_run): report flag (device), its page-locked host
     // copy, the events that order the check stream, and whether a run's flag has not been looked at yet
@@ -2854,6 +2857,90 @@ jxl_status jxl_stage_pack(jxl_ctx* c, const void* const planes[4], const jxl_pac
     return JXL_OK;
 }
 
+}  // extern "C"
+
+// ---- Modular: pairing of squeeze steps for the fused kernel (r5) ---------------------------------------------------------------
+namespace {
+// a V step and the H step that takes its outputs as averages, channel by channel (ModularStream.java:229-254: V_k, H_k of one level)
+bool squeeze_pair_fusable(const ModOp& v, const ModOp& h) {
+    if (v.kind != 4 || h.kind != 4 || v.bt.horizontal || !h.bt.horizontal || v.bt.n != h.bt.n || v.bt.n <= 0) return false;
+    for (int i = 0; i < v.bt.n; i++) {
+        const SqueezeDesc &a = v.bt.d[i], &b = h.bt.d[i];
+        if (b.a != a.o || b.adim != a.other || b.other != a.adim + a.rdim || a.rdim < 1 || b.rdim < 1) return false;
+        if ((int64_t)(a.adim + a.rdim) * (b.adim + b.rdim) >= ((int64_t)1 << 29)) return false;  // 32-bit byte offsets in the kernel
+    }
+    return true;
+}
+
+template <class Alloc>
+bool make_vh(jxl_ctx* c, const SqueezeBatch& v, const SqueezeBatch& h, VHBatch& out, Alloc&& alloc) {
+    out = VHBatch{};
+    out.n = v.n;
+    // H segment length: long segments amortise the warm-up chunk (16 pairs per segment); short ones give a small step enough waves.
+    // The big steps run at the memory system's rate for this access shape from ~1500 waves on (measured: 2040 waves of 17 chunks
+    // beat 4080 of 9 and 8160 of 5), so: the longest segment that still leaves `want` tiles. A step that has only a few hundred
+    // tiles even at 32 pairs is bound by how long ONE tile takes, not by throughput: 16-pair segments (a warm-up chunk and one chunk).
+    const int seg_env = getenv("JXL_VH_SEG") ? atoi(getenv("JXL_VH_SEG")) : 0;  // (read per plan: the parity tests sweep it)
+    const int want = getenv("JXL_VH_TILES") ? atoi(getenv("JXL_VH_TILES")) : 1500;
+    const int small = getenv("JXL_VH_SMALL") ? atoi(getenv("JXL_VH_SMALL")) : 2000;
+    int seg = 256;
+    auto tiles_with = [&](int sg) {
+        int64_t t = 0;
+        for (int i = 0; i < v.n; i++) t += (int64_t)((v.d[i].adim + v.d[i].rdim + 63) / 64) * ((h.d[i].rdim + sg - 1) / sg);
+        return t;
+    };
+    while (seg > 32 && tiles_with(seg) < want) seg >>= 1;
+    if (seg == 32 && tiles_with(32) < small) seg = 16;
+    if (seg_env >= 16) seg = (seg_env + 15) & ~15;
+    int tile0 = 0;
+    for (int i = 0; i < v.n; i++) {
+        VHDesc& d = out.d[i];
+        d.va = v.d[i].a;
+        d.vb = v.d[i].b;
+        d.hb = h.d[i].b;
+        d.o = h.d[i].o;
+        d.w = v.d[i].other;
+        d.ah = v.d[i].adim;
+        d.rh = v.d[i].rdim;
+        d.rw = h.d[i].rdim;
+        d.seg = seg;
+        d.nseg = (d.rw + seg - 1) / seg;
+        d.nstripe = (d.ah + d.rh + 63) / 64;
+        d.tile0 = tile0;
+        tile0 += d.nseg * d.nstripe;
+        const int nsv = (d.rh + 31) / 32;
+        d.side_h = alloc((size_t)d.nseg * (d.ah + d.rh));
+        d.tail_h = alloc((size_t)d.nseg * (d.ah + d.rh));
+        d.side_v = alloc((size_t)nsv * d.w);
+        d.tail_v = alloc((size_t)nsv * d.w);
+        if (!d.side_h || !d.tail_h || !d.side_v || !d.tail_v) return false;
+    }
+    out.n_tiles = tile0;
+    (void)c;
+    return true;
+}
+
+// the segment-boundary arrays a launch leaves behind (checked in the prologue of the next launch, or by k_squeeze_check)
+void checks_of(const SqueezeBatch& bt, std::vector<SqueezeCheck>& out) {
+    out.clear();
+    for (int i = 0; i < bt.n; i++) {
+        const int nseg = squeeze_segments(bt.d[i]);
+        if (nseg > 1) out.push_back(SqueezeCheck{bt.d[i].side, bt.d[i].tail, bt.d[i].other, nseg});
+    }
+}
+void checks_of(const VHBatch& bt, std::vector<SqueezeCheck>& out) {
+    out.clear();
+    for (int i = 0; i < bt.n; i++) {
+        const VHDesc& d = bt.d[i];
+        if (d.nseg > 1) out.push_back(SqueezeCheck{d.side_h, d.tail_h, d.ah + d.rh, d.nseg});
+        const int nsv = (d.rh + 31) / 32;
+        if (nsv > 1) out.push_back(SqueezeCheck{d.side_v, d.tail_v, d.w, nsv});
+    }
+}
+}  // namespace
+
+extern "C" {
+
 // ---- Modular ----------------------------------------------------------------------------------------
 int32_t jxl_modular_default_squeeze_params(const int32_t* widths, const int32_t* heights, int32_t n_channels, int32_t nb_meta,
                                            jxl_squeeze_param* out, int32_t cap) {
@@ -2936,6 +3023,7 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
     for (auto& b : c->mod_bufs) b.release();
     c->mod_bufs.clear();
     c->mod_ops.clear();
+    c->mod_ops_fused.clear();
     c->mod_out.clear();
     auto alloc = [&](size_t n_elems) -> int32_t* {
         c->mod_bufs.emplace_back();
@@ -3035,6 +3123,8 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
             slots = std::max(slots, op.bt.n);
             run++;
         }
+        // r5: a V step whose H partner would stay outside the run pairs with it in the fused kernel instead
+        if (run >= 1 && run < c->mod_ops.size() && !getenv("JXL_SQUEEZE_NO_VH") && squeeze_pair_fusable(c->mod_ops[run - 1], c->mod_ops[run])) run--;
         if (run >= 2) {
             std::vector<SqueezeBatch> steps;
             for (size_t q = 0; q < run; q++) {
@@ -3079,6 +3169,24 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
         for (int j = 0; j < 3; j++) v[kPermutationLut[perm][j]] = t[j];
     }
     c->mod_out = ch;
+    // r5: every V step followed by the H step of the same channels becomes one launch (k_modular_vh.hip)
+    c->mod_ops_fused.clear();
+    if (!getenv("JXL_SQUEEZE_NO_VH")) {
+        bool any = false;
+        for (size_t i = 0; i < c->mod_ops.size();) {
+            if (i + 1 < c->mod_ops.size() && squeeze_pair_fusable(c->mod_ops[i], c->mod_ops[i + 1])) {
+                ModOp f{};
+                f.kind = 6;
+                if (!make_vh(c, c->mod_ops[i].bt, c->mod_ops[i + 1].bt, f.vh, alloc)) return fail(c, JXL_ERR_OOM, "device allocation failed (fused squeeze states)");
+                c->mod_ops_fused.push_back(f);
+                any = true;
+                i += 2;
+            } else {
+                c->mod_ops_fused.push_back(c->mod_ops[i++]);
+            }
+        }
+        if (!any) c->mod_ops_fused.clear();
+    }
     return JXL_OK;
 }
 
@@ -3104,17 +3212,24 @@ jxl_status run_modular_plan(jxl_ctx* c, int mode) {
         (void)hipStreamWaitEvent(s, c->mod_join, 0);
         checks_out = false;
     };
-    // mode 2: the last segmented step whose check has not been launched yet
-    SqueezeBatch pending{};
-    bool have_pending = false;
+    // mode 2: the segment-boundary arrays of the last launch, not compared yet
+    std::vector<SqueezeCheck> pending, mine;
+    int32_t* flag = mode == 2 ? c->mod_flag.as<int32_t>() : nullptr;
     auto flush_pending = [&]() {  // nothing follows that could carry the check: a (tiny) report-only launch of its own
-        if (!have_pending) return;
-        launch_squeeze_verify(pending, s);
-        launches++;
-        have_pending = false;
+        if (pending.empty()) return;
+        launch_squeeze_check(pending.data(), (int)pending.size(), flag, s);
+        launches += ((int)pending.size() + 3) / 4;
+        pending.clear();
     };
-    for (const ModOp& op : c->mod_ops) {
-        if (mode == 2 && op.kind != 4) flush_pending();
+    auto take_pending = [&](int& n_chk, SqueezeCheck* chk) {
+        if ((int)pending.size() > kSqueezeMaxChecks) flush_pending();
+        n_chk = (int)pending.size();
+        for (int i = 0; i < n_chk; i++) chk[i] = pending[i];
+        pending.clear();
+    };
+    const std::vector<ModOp>& ops = (mode == 2 && !c->mod_ops_fused.empty()) ? c->mod_ops_fused : c->mod_ops;
+    for (const ModOp& op : ops) {
+        if (mode == 2 && op.kind != 4 && op.kind != 6) flush_pending();
         switch (op.kind) {
         case 0: launch_inv_hsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, s); break;
         case 1: launch_inv_vsqueeze(op.a, op.adim, op.b, op.rdim, op.other, op.o, s); break;
@@ -3123,14 +3238,11 @@ jxl_status run_modular_plan(jxl_ctx* c, int mode) {
         case 4: {
             SqueezeBatch bt = op.bt;
             if (mode == 2) {
-                bt.flag = c->mod_flag.as<int32_t>();
-                if (have_pending) squeeze_fill_check(pending, bt);
-                have_pending = false;
+                bt.flag = flag;
+                take_pending(bt.n_chk, bt.chk);
                 launch_squeeze_walk(bt, s);
                 if (squeeze_can_fuse_check(bt)) {
-                    pending = bt;
-                    pending.n_chk = 0;
-                    have_pending = true;
+                    checks_of(bt, pending);
                 } else {
                     bt.flag = nullptr;  // (no compact tails: JXL_SQUEEZE_NO_TAIL) check and repair in place, as mode 0
                     bt.n_chk = 0;
@@ -3144,6 +3256,14 @@ jxl_status run_modular_plan(jxl_ctx* c, int mode) {
             break;
         }
         case 5: launch_squeeze_chain(op.chain_dev, op.chain_steps, op.chain_slots, s); break;
+        case 6: {  // (mode 2 only)
+            VHBatch bt = op.vh;
+            bt.flag = flag;
+            take_pending(bt.n_chk, bt.chk);
+            launch_squeeze_vh(bt, s);
+            checks_of(bt, pending);
+            break;
+        }
         }
         launches++;
     }

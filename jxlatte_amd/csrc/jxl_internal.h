@@ -287,8 +287,38 @@ struct SqueezeBatch {
     // of that step's compact side / tail arrays before it starts its own walk and reports a mismatch in `flag`; a 1080p plan is
     // then 13 launches instead of 23 (the check launches were 6 us each on the chain of dependent launches that bounds it)
     int n_chk;
-    SqueezeCheck chk[8];
+    SqueezeCheck chk[16];
 };
+constexpr int kSqueezeMaxChecks = 16;
+
+// r5: a vertical step and the horizontal step that follows it on the same channels (ModularStream.java:229-254 applies them back
+// to back: V_k, H_k produce level k of the squeeze pyramid from level k + 1) as ONE launch -- the V output lives in LDS only.
+// One wave = one tile: 64 output rows (a "stripe": 32 V pairs) x one H segment of `seg` pairs, walked left to right in chunks of
+// 16 H pairs (k_modular_vh.hip). Guessed states, all verified like the segmented walk's (SqueezeCheck): the H chain at a segment
+// start (side_h / tail_h, [nseg][rows]), the V chain at a stripe start (side_v / tail_v, [nstripe][columns]), and the V chain at
+// the three quarter boundaries inside a stripe (compared inside the wave, reported in VHBatch::flag).
+struct VHDesc {
+    const int32_t* va;  // V averages  [ah][w]
+    const int32_t* vb;  // V residuals [rh][w]
+    const int32_t* hb;  // H residuals [ah + rh][rw]
+    int32_t* o;         // output      [ah + rh][w + rw]
+    int w, ah, rh, rw;  // rh >= 1, rw >= 1; ah - rh and w - rw are 0 or 1
+    int seg;            // H pairs per segment (a multiple of 16)
+    int nseg, nstripe;  // ceil(rw / seg), ceil((ah + rh) / 64)
+    int tile0;          // index of this channel's first tile in the launch (tiles: [stripe][segment])
+    int32_t *side_h, *tail_h;  // [nseg][ah + rh]
+    int32_t *side_v, *tail_v;  // [ceil(rh / 32)][w]
+};
+struct VHBatch {
+    int n, n_tiles;
+    VHDesc d[8];
+    int32_t* flag;  // report a mismatch (atomicOr 1); never null
+    int n_chk;      // segment-boundary arrays of an EARLIER step, checked in this launch's prologue
+    SqueezeCheck chk[kSqueezeMaxChecks];
+};
+void launch_squeeze_vh(const VHBatch& bt, hipStream_t s);
+// parallel report-only comparison of segment-boundary arrays (the last step of a plan has no later launch to ride in)
+void launch_squeeze_check(const SqueezeCheck* chk, int n_chk, int32_t* flag, hipStream_t s);
 // Small steps are bound by the time ONE wave needs for its segment (~130 cycles per pair), large ones by bandwidth: the host
 // gives steps of up to 8 Mi samples 32-pair segments with an 8-pair warm-up (measured: 1080p image 0.245 -> 0.195 ms) and
 // keeps 64 + 16 beyond (8K image: 0.78 ms against 0.80 ms with 32 + 8 everywhere).
@@ -304,7 +334,6 @@ void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t che
 void launch_squeeze_walk(const SqueezeBatch& bt, hipStream_t s);
 void launch_squeeze_verify(const SqueezeBatch& bt, hipStream_t s);
 bool squeeze_can_fuse_check(const SqueezeBatch& bt);
-void squeeze_fill_check(const SqueezeBatch& prev, SqueezeBatch& next);
 // a run of small steps in one launch: dev_steps = the steps' SqueezeBatch blocks in device memory, slot i of every step by
 // workgroup i (the caller has checked that slot i of a step depends on slot i of the step before only)
 void launch_squeeze_chain(const SqueezeBatch* dev_steps, int n_steps, int n_slots, hipStream_t s);

@@ -472,15 +472,6 @@ bool squeeze_can_fuse_check(const SqueezeBatch& bt) {
     return any;
 }
 
-void squeeze_fill_check(const SqueezeBatch& prev, SqueezeBatch& next) {
-    next.n_chk = 0;
-    for (int i = 0; i < prev.n; i++) {
-        const int nseg = squeeze_segments(prev.d[i]);
-        if (nseg <= 1) continue;
-        next.chk[next.n_chk++] = SqueezeCheck{prev.d[i].side, prev.d[i].tail, prev.d[i].other, nseg};
-    }
-}
-
 void launch_squeeze_batch(const SqueezeBatch& bt, hipStream_t s, hipStream_t check_stream, hipEvent_t ev) {
     int maxdim, nseg;
     if (!squeeze_grid(bt, maxdim, nseg)) return;

@@ -236,3 +236,108 @@ def test_plan_in_order_repairs_adversarial_rows(ctx, orc, horizontal, monkeypatc
     out = host.ModularStream(ctx, [a, r], [(1 if horizontal else 0, 1, 0, 1)]).applyTransforms()
     assert_bits_equal(out[0], exp, "adversarial plan %s" % ("h" if horizontal else "v"))
     assert ctx.lib.jxl_modular_redo_count(ctx.h) == before
+
+
+# ---- r5: a V step and the H step behind it as one launch (k_modular_vh.hip) ---------------------------------------------------
+def _vh_inputs(rng, htot, wtot, nch=1, big=False):
+    """channel list of a two-step plan (forward order H then V, so the inverse runs V then H): avg, V residuals, H residuals"""
+    ah, rh, aw, rw = (htot + 1) // 2, htot // 2, (wtot + 1) // 2, wtot // 2
+    lo, hi = (-2 ** 31, 2 ** 31 - 1) if big else (-3000, 3000)
+    avg = [rng.integers(lo, hi, size=(ah, aw)).astype(np.int32) for _ in range(nch)]
+    if big:
+        vr = [rng.integers(lo, hi, size=(rh, aw)).astype(np.int32) for _ in range(nch)]
+        hr = [rng.integers(lo, hi, size=(htot, rw)).astype(np.int32) for _ in range(nch)]
+    else:
+        vr = [np.rint(rng.laplace(0, 40, size=(rh, aw))).astype(np.int32) for _ in range(nch)]
+        hr = [np.rint(rng.laplace(0, 40, size=(htot, rw))).astype(np.int32) for _ in range(nch)]
+    return avg + vr + hr, [(1, 1, 0, nch), (0, 1, 0, nch)]
+
+
+@pytest.mark.parametrize("htot,wtot", [(2, 2), (3, 3), (5, 34), (64, 32), (64, 66), (65, 65), (66, 130), (127, 97), (128, 256), (130, 257),
+                                       (193, 67), (200, 1030), (321, 514), (1080, 1920)])
+@pytest.mark.parametrize("seg", [None, "16", "32", "64"])
+def test_fused_vh_pair(ctx, orc, htot, wtot, seg, monkeypatch):
+    """V + H of one level in one launch: every edge the tile walk has -- one stripe / several, ragged last stripe, odd height (the
+    copied last row) and odd width (the copied last column), one segment / several with a ragged last one, the extra chunk that
+    only holds the odd column -- against the oracle's two serial steps"""
+    if seg is None:
+        monkeypatch.delenv("JXL_VH_SEG", raising=False)
+    else:
+        monkeypatch.setenv("JXL_VH_SEG", seg)
+    rng = np.random.default_rng(htot * 131 + wtot)
+    chans, sp = _vh_inputs(rng, htot, wtot)
+    ms = host.ModularStream(ctx, chans, sp)
+    out = ms.applyTransforms()
+    exp = orc.modular_apply(chans, sp)
+    assert len(out) == len(exp) == 1 and out[0].shape == (htot, wtot)
+    assert_bits_equal(out[0], exp[0], "fused V+H %dx%d seg %s" % (htot, wtot, seg))
+    assert ctx.lib.jxl_modular_last_launch_count(ctx.h) <= 2  # the pair + (at most) one check launch: the fused kernel ran
+
+
+def test_fused_vh_three_channels_and_rerun(ctx, orc, monkeypatch):
+    monkeypatch.setenv("JXL_VH_SEG", "32")
+    rng = np.random.default_rng(77)
+    chans, sp = _vh_inputs(rng, 150, 201, nch=3)
+    ms = host.ModularStream(ctx, chans, sp)
+    ms.begin()
+    exp = orc.modular_apply(chans, sp)
+    for run in range(2):
+        ms.run()
+        got = ms.getDecodedBuffer()
+        assert len(got) == 3
+        for i in range(3):
+            assert_bits_equal(got[i], exp[i], "channel %d run %d" % (i, run))
+
+
+def test_fused_vh_int32_extremes_take_the_exact_path(ctx, orc):
+    """operands outside the range guard of the short tendency form (modular_tend.h): the chunk is walked with the reference's
+    long form; wrap-around as in Java"""
+    rng = np.random.default_rng(3)
+    chans, sp = _vh_inputs(rng, 130, 140, big=True)
+    before = ctx.lib.jxl_modular_redo_count(ctx.h)
+    out = host.ModularStream(ctx, chans, sp).applyTransforms()
+    assert_bits_equal(out[0], orc.modular_apply(chans, sp)[0], "extremes")
+    # mixed: ordinary data with a few extreme samples
+    chans, sp = _vh_inputs(rng, 130, 140)
+    chans[0][5, 7] = 2 ** 31 - 1
+    chans[1][9, 3] = -2 ** 31
+    chans[2][100, 50] = 2 ** 30
+    out = host.ModularStream(ctx, chans, sp).applyTransforms()
+    assert_bits_equal(out[0], orc.modular_apply(chans, sp)[0], "mixed extremes")
+    assert ctx.lib.jxl_modular_redo_count(ctx.h) >= before  # (white-noise extremes may or may not forget their start)
+
+
+@pytest.mark.parametrize("axis", ["h", "v"])
+def test_fused_vh_reports_adversarial_chains_and_redoes_in_order(ctx, orc, axis, monkeypatch):
+    """chains that never forget their start (see _adversarial) across an H segment boundary / a V stripe or quarter boundary: the
+    fused launch reports, the plan runs again with the one-step kernels in order, and the result is the serial walk's"""
+    monkeypatch.setenv("JXL_VH_SEG", "32")
+    rng = np.random.default_rng(21)
+    chans, sp = _vh_inputs(rng, 200, 300)
+    if axis == "h":  # the V output is what the H step sees as averages: the forward V step of the adversarial rows
+        a, r = _adversarial(150, 200)              # H step: 200 rows, 150 pairs
+        vavg, vres = orc.fwd_vsqueeze(a)
+        chans = [vavg, vres, r]
+    else:
+        a, r = _adversarial(100, 150)              # as columns: 100 V pairs, 150 columns
+        chans = [a.T.copy(), r.T.copy(), np.rint(rng.laplace(0, 40, size=(200, 150))).astype(np.int32)]
+    before = ctx.lib.jxl_modular_redo_count(ctx.h)
+    out = host.ModularStream(ctx, chans, sp).applyTransforms()
+    assert_bits_equal(out[0], orc.modular_apply(chans, sp)[0], "adversarial %s" % axis)
+    assert ctx.lib.jxl_modular_redo_count(ctx.h) == before + 1
+
+
+def test_fused_plan_equals_unfused_plan(ctx, orc, monkeypatch):
+    """the default plan of a 3-channel image with and without the pair kernel (JXL_SQUEEZE_NO_VH): same samples, fewer launches"""
+    mod = synth.make_modular_frame(611, 437, channels=3, seed=4)
+    exp = orc.modular_apply(mod["chans"], mod["sp"])
+    ms = host.ModularStream(ctx, mod["chans"], mod["sp"])
+    out = ms.applyTransforms()
+    fused_launches = ctx.lib.jxl_modular_last_launch_count(ctx.h)
+    monkeypatch.setenv("JXL_SQUEEZE_NO_VH", "1")
+    ms2 = host.ModularStream(ctx, mod["chans"], mod["sp"])
+    out2 = ms2.applyTransforms()
+    for i in range(3):
+        assert_bits_equal(out[i], exp[i], "fused channel %d" % i)
+        assert_bits_equal(out2[i], exp[i], "unfused channel %d" % i)
+    assert fused_launches < ctx.lib.jxl_modular_last_launch_count(ctx.h)

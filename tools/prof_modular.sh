@@ -10,7 +10,7 @@ NL=$NL python3 - <<'PY'
 import csv, os, collections
 R=os.environ["GRAFT_REPO_ROOT"]
 rows=list(csv.DictReader(open(R+"/gpurun_out/prof_mod/p_kernel_trace.csv")))
-rows=[r for r in rows if "squeeze" in r["Kernel_Name"] or "k_vh" in r["Kernel_Name"] or "modular" in r["Kernel_Name"] or "k_rct" in r["Kernel_Name"]]
+rows=[r for r in rows if "squeeze" in r["Kernel_Name"] or "k_inv_vh" in r["Kernel_Name"] or "modular" in r["Kernel_Name"] or "k_rct" in r["Kernel_Name"]]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 n=len(rows)//4  # 1 warm-up + 3 steps
 last=rows[-n:]
