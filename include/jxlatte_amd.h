@@ -197,10 +197,15 @@ jxl_status jxl_vardct_set_lfgroup_lfquant(jxl_ctx* ctx, const jxl_lfquant_desc* 
 /* quantizedCoeffs of one (pass, group) (HFCoefficients.java:43,68): q[c] is [gh][gw] with row
  * stride[c] elements; gh,gw = Frame.getGroupSize(group). pass > 0 accumulates
  * (PassGroup.java:174-200).
- * Buffer lifetime: pageable sources (and page-locked ones that are not 16-byte aligned in address and row stride) are copied
- * before the call returns and may be reused at once. Aligned page-locked sources (jxl_host_alloc) are read by the device in
- * place, asynchronously: keep them unchanged until jxl_vardct_run / finish_frame of this frame has returned or
- * jxl_ctx_synchronize has. The call itself never waits for the device except when more than 8 puts are still in flight. */
+ * Buffer lifetime -- NOT "retains nothing after the call" for every source: pageable sources (and page-locked ones that are
+ * not 16-byte aligned in address and row stride) are copied before the call returns and may be reused at once. Aligned
+ * page-locked sources (jxl_host_alloc, or memory the caller registered) are read by the DEVICE in place, asynchronously, by a
+ * kernel queued on the context's stream: keep them unchanged until a call that waits for that stream has returned --
+ * jxl_vardct_finish_frame / jxl_vardct_read_output / jxl_vardct_read_output_wait of this frame, or jxl_ctx_synchronize
+ * (jxl_vardct_run only queues work). A caller that wants the copy semantics with page-locked memory passes a pointer that is
+ * not 16-byte aligned, or copies itself. The JNI shim's callers (integration/jni/GpuFrameBridge.java) hand over fresh pageable
+ * direct ByteBuffers: always the copying path. The call itself never waits for the device except when more than 8 puts are
+ * still in flight. */
 jxl_status jxl_vardct_put_group(jxl_ctx* ctx, int32_t pass, int32_t group,
                                 const int32_t* const q[3], const int32_t stride[3]);
 /* The same with 16-bit samples -- the wire format for the PCIe leg: quantised HF coefficients of photographic content fit
@@ -220,6 +225,13 @@ jxl_status jxl_vardct_map_coeffs_i16(jxl_ctx* ctx, int16_t* planes[3], int32_t s
 /* Rows of the three mapped planes ((paddedHeight >> jpegUpsamplingY[c]), HFCoefficients.java:64-69): plane c holds
  * rows[c] * strides[c] samples. The JNI shim sizes its direct ByteBuffers from this, never from a caller-supplied count. */
 jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* ctx, int32_t rows[3]);
+/* Geometry of the open frame, for callers that must size buffers from the library's own numbers (the JNI shim checks every
+ * direct buffer it is handed against these): info[0..2] = plane width of channel c (paddedWidth >> jpegUpsamplingX[c]),
+ * info[3..5] = plane height, info[6..7] = the two shifts (x, y) of channel 0, [8..9] of channel 1, [10..11] of channel 2,
+ * info[12] = bytes per output sample. Group g of a frame covers Frame.getGroupLocation / getGroupSize (J/frame/Frame.java:767-786):
+ * jxl_vardct_group_size gives its width and height per channel. */
+jxl_status jxl_vardct_geometry(jxl_ctx* ctx, int32_t info[13]);
+jxl_status jxl_vardct_group_size(jxl_ctx* ctx, int32_t group, int32_t gw[3], int32_t gh[3]);
 jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* ctx);
 /* The same pair without the zero-fill (r4): a decoder writes EVERY sample of every group it decodes (HFCoefficients.java:76-138
  * leaves the untouched samples of its fresh int[][] at zero -- the caller of this form stores those zeros itself, or keeps its

@@ -125,6 +125,24 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_setLFGroup(
         jobject lfX, jobject lfY, jobject lfB) {
     jxl_ctx* c = ctx_of(e, self);
     jxl_lfgroup_desc d;
+    int32_t geo[13];
+    CHECK(jxl_vardct_geometry(c, geo));
+    if (cellsH <= 0 || cellsW <= 0 || cellsH > 256 || cellsW > 256 || nBlocks < 0) {
+        bad_arg(e, "jxlatte_amd: LF group size out of range");
+        return;
+    }
+    {   /* every grid the library will read, sized from the stated cell counts and the frame's own subsampling shifts */
+        const jlong cells = area(cellsH, cellsW), tiles = area((cellsH + 7) / 8, (cellsW + 7) / 8);
+        NEED(dctSelect, cells);
+        NEED(hfMul, 4 * cells);
+        NEED(sharpness, 4 * cells);
+        NEED(xFromY, 4 * tiles);
+        NEED(bFromY, 4 * tiles);
+        NEED(blockYX, 8 * (jlong)nBlocks);
+        NEED_OPT(lfX, 4 * area(cellsH >> geo[7], cellsW >> geo[6]));
+        NEED_OPT(lfY, 4 * area(cellsH >> geo[9], cellsW >> geo[8]));
+        NEED_OPT(lfB, 4 * area(cellsH >> geo[11], cellsW >> geo[10]));
+    }
     memset(&d, 0, sizeof d);
     d.lfg_y = lfgY; d.lfg_x = lfgX; d.cells_h = cellsH; d.cells_w = cellsW;
     d.dct_select = (const uint8_t*)ADDR(dctSelect);
@@ -143,11 +161,20 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_setLFGroupQ
         jint bFactorLF, jboolean adaptiveSmoothing) {
     jxl_ctx* c = ctx_of(e, self);
     jxl_lfquant_desc d;
+    int32_t geo[13];
+    CHECK(jxl_vardct_geometry(c, geo));
+    if (cellsH <= 0 || cellsW <= 0 || cellsH > 256 || cellsW > 256) {
+        bad_arg(e, "jxlatte_amd: LF group size out of range");
+        return;
+    }
+    NEED(qX, 4 * area(cellsH >> geo[7], cellsW >> geo[6]));
+    NEED(qY, 4 * area(cellsH >> geo[9], cellsW >> geo[8]));
+    NEED(qB, 4 * area(cellsH >> geo[11], cellsW >> geo[10]));
     memset(&d, 0, sizeof d);
     d.lfg_y = lfgY; d.lfg_x = lfgX; d.cells_h = cellsH; d.cells_w = cellsW;
     d.lf_quant[0] = (const int32_t*)ADDR(qX); d.lf_quant[1] = (const int32_t*)ADDR(qY); d.lf_quant[2] = (const int32_t*)ADDR(qB);
     d.extra_precision = extraPrecision;
-    (*e)->GetFloatArrayRegion(e, scaledDequant, 0, 3, d.scaled_dequant);
+    GETF(scaledDequant, 3, d.scaled_dequant);
     d.x_factor_lf = xFactorLF; d.b_factor_lf = bFactorLF; d.adaptive_smoothing = adaptiveSmoothing ? 1 : 0;
     CHECK(jxl_vardct_set_lfgroup_lfquant(c, &d));
 }
@@ -155,16 +182,46 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_setLFGroupQ
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_putGroup(JNIEnv* e, jobject self, jint pass, jint group, jobject qx,
         jobject qy, jobject qb, jint sx, jint sy, jint sb) {
     jxl_ctx* c = ctx_of(e, self);
-    const int32_t* q[3] = {(const int32_t*)ADDR(qx), (const int32_t*)ADDR(qy), (const int32_t*)ADDR(qb)};
     const int32_t s[3] = {sx, sy, sb};
+    int32_t gw[3], gh[3];
+    CHECK(jxl_vardct_group_size(c, group, gw, gh));
+    {   /* rows of gw samples at the caller's stride: (gh - 1) * stride + gw samples are read from each buffer */
+        jobject b[3] = {qx, qy, qb};
+        for (int ch = 0; ch < 3; ch++) {
+            if (s[ch] < gw[ch]) {
+                bad_arg(e, "jxlatte_amd: putGroup stride shorter than the group's rows");
+                return;
+            }
+            if (!has_room(e, b[ch], (jlong)sizeof(int32_t) * (gh[ch] > 0 ? (jlong)(gh[ch] - 1) * s[ch] + gw[ch] : 0))) {
+                bad_arg(e, "jxlatte_amd: putGroup coefficient buffer missing or too small for the group");
+                return;
+            }
+        }
+    }
+    const int32_t* q[3] = {(const int32_t*)ADDR(qx), (const int32_t*)ADDR(qy), (const int32_t*)ADDR(qb)};
     CHECK(jxl_vardct_put_group(c, pass, group, q, s));
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_putGroupI16(JNIEnv* e, jobject self, jint pass, jint group, jobject qx,
         jobject qy, jobject qb, jint sx, jint sy, jint sb) {
     jxl_ctx* c = ctx_of(e, self);
-    const int16_t* q[3] = {(const int16_t*)ADDR(qx), (const int16_t*)ADDR(qy), (const int16_t*)ADDR(qb)};
     const int32_t s[3] = {sx, sy, sb};
+    int32_t gw[3], gh[3];
+    CHECK(jxl_vardct_group_size(c, group, gw, gh));
+    {   /* rows of gw samples at the caller's stride: (gh - 1) * stride + gw samples are read from each buffer */
+        jobject b[3] = {qx, qy, qb};
+        for (int ch = 0; ch < 3; ch++) {
+            if (s[ch] < gw[ch]) {
+                bad_arg(e, "jxlatte_amd: putGroupI16 stride shorter than the group's rows");
+                return;
+            }
+            if (!has_room(e, b[ch], (jlong)sizeof(int16_t) * (gh[ch] > 0 ? (jlong)(gh[ch] - 1) * s[ch] + gw[ch] : 0))) {
+                bad_arg(e, "jxlatte_amd: putGroupI16 coefficient buffer missing or too small for the group");
+                return;
+            }
+        }
+    }
+    const int16_t* q[3] = {(const int16_t*)ADDR(qx), (const int16_t*)ADDR(qy), (const int16_t*)ADDR(qb)};
     CHECK(jxl_vardct_put_group_i16(c, pass, group, q, s));
 }
 
@@ -250,6 +307,19 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_run(JNIEnv*
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
         jlong stride) {
     jxl_ctx* c = ctx_of(e, self);
+    int32_t geo[13];
+    CHECK(jxl_vardct_geometry(c, geo));
+    {   /* H rows of W samples of the output sample size, `stride` samples apart (0: tightly packed) */
+        const jlong st = stride > 0 ? stride : geo[0];
+        if (st < geo[0]) {
+            bad_arg(e, "jxlatte_amd: readOutput stride shorter than a row");
+            return;
+        }
+        const jlong need = (jlong)geo[12] * ((jlong)(geo[3] - 1) * st + geo[0]);
+        NEED(ox, need);
+        NEED(oy, need);
+        NEED(ob, need);
+    }
     void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
     CHECK(jxl_vardct_read_output(c, out, stride));
 }
@@ -258,6 +328,19 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutputBegin(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
         jlong stride) {
     jxl_ctx* c = ctx_of(e, self);
+    int32_t geo[13];
+    CHECK(jxl_vardct_geometry(c, geo));
+    {   /* H rows of W samples of the output sample size, `stride` samples apart (0: tightly packed) */
+        const jlong st = stride > 0 ? stride : geo[0];
+        if (st < geo[0]) {
+            bad_arg(e, "jxlatte_amd: readOutputBegin stride shorter than a row");
+            return;
+        }
+        const jlong need = (jlong)geo[12] * ((jlong)(geo[3] - 1) * st + geo[0]);
+        NEED(ox, need);
+        NEED(oy, need);
+        NEED(ob, need);
+    }
     void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
     CHECK(jxl_vardct_read_output_begin(c, out, stride));
 }

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libjxlatte_amd.so")
-SOURCES = ["k_idct.hip", "k_idct_wg3.hip", "k_idct_wave.hip", "k_restore.hip", "k_restore_fused.hip", "k_restore_fused_gen.hip", "k_restore_fused_q.hip", "k_restore_stream.hip", "k_modular.hip", "k_modular_vh.hip", "k_lf.hip", "k_post.hip", "host.hip"]
+SOURCES = ["k_idct.hip", "k_idct_wg3.hip", "k_restore.hip", "k_restore_fused.hip", "k_restore_fused_gen.hip", "k_restore_fused_q.hip", "k_modular.hip", "k_modular_vh.hip", "k_lf.hip", "k_post.hip", "host.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # k_restore_fused: hipcc's SLP vectoriser packs the EPF distance terms into v_pk_* pairs but pays for it with ~50 register
 # moves and 35 v_and (abs) per channel iteration; scalar code with free |x| source modifiers is 12 % faster (measured).
 # k_idct: the IDCT cores use explicit packed vectors; auto-SLP on the 8x8 special transforms costs 19 % (same symptom).
-EXTRA = {"k_restore_fused": ["-fno-slp-vectorize"], "k_restore_fused_gen": ["-fno-slp-vectorize"], "k_restore_fused_q": ["-fno-slp-vectorize"], "k_restore_stream": ["-fno-slp-vectorize"], "k_idct": ["-fno-slp-vectorize"], "k_idct_wg3": ["-fno-slp-vectorize"], "k_idct_wave": ["-fno-slp-vectorize"]}
+EXTRA = {"k_restore_fused": ["-fno-slp-vectorize"], "k_restore_fused_gen": ["-fno-slp-vectorize"], "k_restore_fused_q": ["-fno-slp-vectorize"], "k_idct": ["-fno-slp-vectorize"], "k_idct_wg3": ["-fno-slp-vectorize"]}
 
 
 def _deps():

@@ -120,7 +120,8 @@ struct jxl_ctx {
     bool coeff_zero_pending = false;   // the coefficient planes have not been zeroed for this frame yet (put_group / run do it; a
                                        // commit of the mapped planes overwrites every sample and needs none)
     bool out_zero_pending = false;     // likewise the transform output planes: only needed when the varblocks do not tile the frame
-    bool blocks_cover = false;         // (finalize_tables) every 8x8 cell belongs to a varblock
+    bool blocks_cover = false;         // (finalize_tables) every 8x8 cell belongs to exactly one varblock
+    std::vector<uint8_t> cell_mark;    // its proof: one mark per cell
     bool llf_alias = false;            // no kernel writes the llf planes for this frame: they ARE the lf planes (no copy)
     size_t tab_fixed = 0, off_hfm = 0, off_sharp = 0, off_kx = 0, off_kb = 0, off_lf[3] = {0, 0, 0};
     HSpan<int32_t> h_hf_mul, h_sharp;
@@ -189,9 +190,6 @@ struct jxl_ctx {
     int32_t h_woffs_in[51] = {};
     DevBuf wg3_items[2];       // spatially ordered item lists of the two k_idct_wg3 classes (wg3_item_table)
     int wg3_item_count[2] = {0, 0};
-    std::vector<IdctSegment> wave_segs;  // the types k_idct_wave handles (frames without chroma subsampling)
-    DevBuf wave_items[2];                // their item lists by launch class (wave_item_table)
-    int wave_item_count[2] = {0, 0};
     std::vector<BatchLaunch> batch_launches;
     hipEvent_t batch_ev = nullptr;
     bool timing = false;
@@ -210,8 +208,6 @@ struct jxl_ctx {
     int n_aux = 1;
     hipStream_t aux[kAux] = {};
     hipEvent_t fork_ev = nullptr, llf_ev = nullptr, join_ev[kAux] = {};
-    hipStream_t wave_side[2] = {nullptr, nullptr};  // k_idct_wave's own side streams (it waits for nothing but the frame's inputs)
-    hipEvent_t wave_fork_ev = nullptr, wave_join_ev[2] = {nullptr, nullptr};
 
     // ---- Modular state
     std::vector<DevBuf> mod_bufs;
@@ -476,6 +472,10 @@ jxl_status finalize_tables(jxl_ctx* c) {
         for (int t = 0; t < NTY; t++) cells += t_count[t] * (size_t)(JXL_TT[t].ph / 8) * (size_t)(JXL_TT[t].pw / 8);
         c->blocks_cover = !c->sub && cells == (size_t)c->bh * c->bw;
     }
+    // ... if none of them overlap: the C ABI accepts any block list, so the claim is checked with one mark per cell (a double mark
+    // plus holes of the same total area would leave cells that are neither written nor zero-filled: stale samples of the
+    // previous frame on this context where the reference's ImageBuffer starts zeroed)
+    if (c->blocks_cover) c->cell_mark.assign((size_t)c->bh * c->bw, 0);
     {
         std::vector<int32_t> stamp((size_t)c->th * c->tw, -1);
         DevBlock* out = c->h_blocks.data();
@@ -489,6 +489,16 @@ jxl_status finalize_tables(jxl_ctx* c) {
                     return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock (%d,%d) type %u leaves the frame", b.cy, b.cx, b.type);
                 const int ty0 = py0 >> 6, tx0 = px0 >> 6, ty1 = (py0 + ph - 1) >> 6, tx1 = (px0 + pw - 1) >> 6;
                 if (ty1 - ty0 > 4 || tx1 - tx0 > 4) return fail(c, JXL_ERR_INVALID_BITSTREAM, "varblock spans too many tiles");
+                if (c->blocks_cover) {
+                    uint8_t* m = c->cell_mark.data() + (size_t)b.cy * c->bw + b.cx;
+                    uint8_t seen = 0;
+                    for (int y = 0; y < ph / 8; y++, m += c->bw)
+                        for (int x = 0; x < pw / 8; x++) {
+                            seen |= m[x];
+                            m[x] = 1;
+                        }
+                    if (seen) c->blocks_cover = false;  // overlapping varblocks: some cell is uncovered, the planes are zero-filled
+                }
                 uint32_t mask = 0;
                 if (ty0 == ty1 && tx0 == tx1) {  // one tile (every 8x8 block: five blocks in six of a photographic frame)
                     int32_t& sp = stamp[(size_t)ty0 * c->tw + tx0];
@@ -527,7 +537,6 @@ jxl_status finalize_tables(jxl_ctx* c) {
     std::vector<WorkItem> items;
     c->type_launches.clear();
     c->special_launches.clear();
-    c->wave_segs.clear();
     static const int kOrder[] = {18, 19, 20, 5, 10, 11, 4, 8, 9, 6, 7, 0};  // longest-running kernels first
     static const int kSpecial[] = {14, 15, 16, 17, 1, 2, 3, 12, 13};
     bool seg_overflow = false;
@@ -553,10 +562,6 @@ jxl_status finalize_tables(jxl_ctx* c) {
         for (int t : kOrder) {
             if (lists[t].empty()) continue;
             const IdctSegment sg{t, (int)first_of[t], (int)lists[t].size()};
-            if (channel < 0 && wave_handles(t)) {  // k_idct_wave.hip: one wave per item, LLF inside the item
-                c->wave_segs.push_back(sg);
-                continue;
-            }
             const int cls = (use_wg3 && channel < 0 && wg3_handles(t)) ? (wg3_big(t) ? 3 : 2) : idct_class_of(t);
             for (auto& l : cl)
                 if (l.cls == cls) l.segs.push_back(sg);
@@ -658,7 +663,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     }
     const size_t nc = (size_t)c->bh * c->bw, nt = (size_t)c->th * c->tw;
     // item lists of the persistent / wave kernels
-    std::vector<int> wg3_tab[2], wave_tab[2];
+    std::vector<int> wg3_tab[2];
     {
         static const bool spatial = !(getenv("JXL_WG3_SPATIAL") && atoi(getenv("JXL_WG3_SPATIAL")) == 0);
         for (int k = 0; k < 2; k++) {
@@ -668,10 +673,6 @@ jxl_status finalize_tables(jxl_ctx* c) {
                 wg3_item_table(c->h_blocks.data(), c->bw, tl.segs.data(), (int)tl.segs.size(), k, c->woffs, spatial, wg3_tab[k], wg3_grid_cap(k == 1));
                 c->wg3_item_count[k] = (int)(wg3_tab[k].size() / 8);
             }
-            c->wave_item_count[k] = 0;
-            if (c->wave_segs.empty()) continue;
-            wave_item_table(c->h_blocks.data(), c->bw, c->wave_segs.data(), (int)c->wave_segs.size(), k, wave_tab[k]);
-            c->wave_item_count[k] = (int)(wave_tab[k].size() / 4);
         }
     }
     mark("item tables");
@@ -692,12 +693,10 @@ jxl_status finalize_tables(jxl_ctx* c) {
     o = tab_up(o + std::max<size_t>(16, n_blk));
     const size_t off_items = o, n_items = sizeof(WorkItem) * items.size();
     o = tab_up(o + std::max<size_t>(16, n_items));
-    size_t off_wg3[2], off_wave[2];
+    size_t off_wg3[2];
     for (int k = 0; k < 2; k++) {
         off_wg3[k] = o;
         o = tab_up(o + std::max<size_t>(16, sizeof(int) * wg3_tab[k].size()));
-        off_wave[k] = o;
-        o = tab_up(o + std::max<size_t>(16, sizeof(int) * wave_tab[k].size()));
     }
     const size_t total = o;
     if (!tab_reserve(c, total, c->tab_fixed)) return fail(c, JXL_ERR_OOM, "host allocation failed (table staging)");
@@ -706,7 +705,6 @@ jxl_status finalize_tables(jxl_ctx* c) {
     if (n_items) memcpy(c->h_tab + off_items, items.data(), n_items);
     for (int k = 0; k < 2; k++) {
         if (!wg3_tab[k].empty()) memcpy(c->h_tab + off_wg3[k], wg3_tab[k].data(), sizeof(int) * wg3_tab[k].size());
-        if (!wave_tab[k].empty()) memcpy(c->h_tab + off_wave[k], wave_tab[k].data(), sizeof(int) * wave_tab[k].size());
     }
     if (total > c->tab.cap || !c->tab.p) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // kernels of an earlier frame may still read the old arena
@@ -726,10 +724,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
         for (int i = 0; i < 3; i++) c->lf[i].view(d + c->off_lf[i], 4 * nc);
         c->blocks.view(d + off_blocks, std::max<size_t>(16, n_blk));
         c->items.view(d + off_items, std::max<size_t>(16, n_items));
-        for (int k = 0; k < 2; k++) {
-            c->wg3_items[k].view(d + off_wg3[k], sizeof(int) * wg3_tab[k].size());
-            c->wave_items[k].view(d + off_wave[k], sizeof(int) * wave_tab[k].size());
-        }
+        for (int k = 0; k < 2; k++) c->wg3_items[k].view(d + off_wg3[k], sizeof(int) * wg3_tab[k].size());
     }
     // row f1: LF groups handed over as integers are dequantised + smoothed on the device, over the uploaded planes
     for (const auto& job : c->lf_jobs) {
@@ -1145,14 +1140,6 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->llf_ev, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&c->wave_fork_ev, hipEventDisableTiming);
-    // (only where the experimental wave kernels are switched on: every stream a context creates shifts the round-robin mapping
-    // of all later streams onto the 4 hardware queues -- see n_aux)
-    static const bool wave_own_streams = !(getenv("JXL_WAVE_STREAMS") && atoi(getenv("JXL_WAVE_STREAMS")) == 0);
-    for (int i = 0; i < 2 && wave_handles(0) && wave_own_streams; i++) {
-        (void)hipStreamCreateWithFlags(&c->wave_side[i], hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&c->wave_join_ev[i], hipEventDisableTiming);
-    }
     if (const char* e = getenv("JXL_AUX_STREAMS")) c->n_aux = std::max(0, std::min((int)jxl_ctx::kAux, atoi(e)));
     // (r3: side streams created with hipStreamCreateWithPriority at the highest priority -- meant to keep the few long-running
     // workgroups of the 64-point and special launches from queueing behind the machine-filling main launch -- started those
@@ -1197,11 +1184,6 @@ void jxl_ctx_destroy(jxl_ctx* c) {
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->llf_ev) (void)hipEventDestroy(c->llf_ev);
-    if (c->wave_fork_ev) (void)hipEventDestroy(c->wave_fork_ev);
-    for (int i = 0; i < 2; i++) {
-        if (c->wave_join_ev[i]) (void)hipEventDestroy(c->wave_join_ev[i]);
-        if (c->wave_side[i]) (void)hipStreamDestroy(c->wave_side[i]);
-    }
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
     c->batch_args.release();
     c->batch_wg3_args.release();
@@ -1218,8 +1200,6 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     c->h_map16 = nullptr;
     c->wg3_items[0].release();
     c->wg3_items[1].release();
-    c->wave_items[0].release();
-    c->wave_items[1].release();
     c->batch_restore_args.release();
     for (int i = 0; i < jxl_ctx::kAux; i++) {
         if (c->aux[i]) { (void)hipStreamSynchronize(c->aux[i]); (void)hipStreamDestroy(c->aux[i]); }
@@ -1538,15 +1518,24 @@ static jxl_status put_group_t(jxl_ctx* c, int32_t pass, int32_t group, const T* 
     if (!in_place) {
         constexpr size_t kSlot = 3 * (size_t)256 * 256 * sizeof(int32_t);
         if (!c->h_grp) {
-            if (hipHostMalloc(&c->h_grp, kSlot * jxl_ctx::kGrpSlots, hipHostMallocDefault) != hipSuccess || !c->h_grp) {
+            // all or nothing: the ring is published (h_grp set) only when its device address and every event exist, so a
+            // failure here can never leave a later call with a null device address or null events
+            void *hp = nullptr, *dp = nullptr;
+            hipEvent_t ev[jxl_ctx::kGrpSlots] = {};
+            bool ok = hipHostMalloc(&hp, kSlot * jxl_ctx::kGrpSlots, hipHostMallocDefault) == hipSuccess && hp;
+            const bool have_mem = ok;
+            ok = ok && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp;
+            for (int i = 0; i < jxl_ctx::kGrpSlots && ok; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
                 (void)hipGetLastError();
-                c->h_grp = nullptr;
-                return fail(c, JXL_ERR_OOM, "page-locked allocation of the group staging ring failed");
+                for (int i = 0; i < jxl_ctx::kGrpSlots; i++)
+                    if (ev[i]) (void)hipEventDestroy(ev[i]);
+                if (hp && have_mem) (void)hipHostFree(hp);
+                return fail(c, have_mem ? JXL_ERR_DEVICE : JXL_ERR_OOM, "set-up of the page-locked group staging ring failed");
             }
-            void* dp = nullptr;
-            if (hipHostGetDevicePointer(&dp, c->h_grp, 0) != hipSuccess || !dp) return fail(c, JXL_ERR_DEVICE, "no device address for the group staging ring");
+            for (int i = 0; i < jxl_ctx::kGrpSlots; i++) c->grp_ev[i] = ev[i];
             c->h_grp_dev = dp;
-            for (int i = 0; i < jxl_ctx::kGrpSlots; i++) HIP_TRY(c, hipEventCreateWithFlags(&c->grp_ev[i], hipEventDisableTiming));
+            c->h_grp = hp;
         }
         const int slot = c->grp_slot;
         c->grp_slot = (slot + 1) % jxl_ctx::kGrpSlots;
@@ -1620,6 +1609,34 @@ jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* c, int32_t rows[3]) {
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
     if (!rows) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null argument");
     for (int ch = 0; ch < 3; ch++) rows[ch] = c->H >> c->sy[ch];
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_geometry(jxl_ctx* c, int32_t info[13]) {
+    if (!c) return JXL_ERR_INVALID_ARGUMENT;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    if (!info) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null argument");
+    for (int ch = 0; ch < 3; ch++) {
+        info[ch] = c->W >> c->sx[ch];
+        info[3 + ch] = c->H >> c->sy[ch];
+        info[6 + 2 * ch] = c->sx[ch];
+        info[7 + 2 * ch] = c->sy[ch];
+    }
+    info[12] = jxl_vardct_out_elem_size(c);
+    return JXL_OK;
+}
+
+jxl_status jxl_vardct_group_size(jxl_ctx* c, int32_t group, int32_t gw[3], int32_t gh[3]) {
+    if (!c) return JXL_ERR_INVALID_ARGUMENT;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    const int grs = ceil_div(c->W, 256), gcs = ceil_div(c->H, 256);
+    if (!gw || !gh || group < 0 || group >= grs * gcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "group index out of range");
+    const int gy = group / grs, gx = group % grs;
+    const int w = std::min(256, c->W - gx * 256), h = std::min(256, c->H - gy * 256);
+    for (int ch = 0; ch < 3; ch++) {
+        gw[ch] = w >> c->sx[ch];
+        gh[ch] = h >> c->sy[ch];
+    }
     return JXL_OK;
 }
 
@@ -1769,36 +1786,6 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 for (int q = 0; q < wl.n_seg; q++) any_llf = any_llf || (wl.seg[q].type != 0 && !wl.llf_in_item);
             }
         }
-        // k_idct_wave: depends on nothing but the frame's inputs (its LLF is computed inside the items), so it starts at once
-        // on a side stream of its own and runs beside the LLF launch and the kernels of the other types
-        hipStream_t wave_stream[2] = {nullptr, nullptr};
-        WaveArgs wv[2];
-        static const bool wave_first = getenv("JXL_WAVE_FIRST") && atoi(getenv("JXL_WAVE_FIRST")) != 0;
-        {
-            const bool others = !c->type_launches.empty() || !c->special_launches.empty() || c->large_count > 0;
-            bool forked = false;
-            for (int k = 1; k >= 0; k--) {  // the 32-point class first: its items run longest
-                wv[k].n_items = 0;
-                if (c->wave_item_count[k] <= 0) continue;
-                wv[k].f = f;
-                wv[k].blocks = blocks;
-                wv[k].o0 = A[0]; wv[k].o1 = A[1]; wv[k].o2 = A[2];
-                wv[k].items = c->wave_items[k].as<int>();
-                wv[k].n_items = c->wave_item_count[k];
-                const bool last = !others && (k == 0 || c->wave_item_count[0] <= 0);  // the stage's last launch may use the main stream
-                wave_stream[k] = (!last && c->wave_side[k]) ? c->wave_side[k] : s;
-                if (wave_stream[k] != s) {
-                    if (!forked) (void)hipEventRecord(c->wave_fork_ev, s);
-                    forked = true;
-                    (void)hipStreamWaitEvent(wave_stream[k], c->wave_fork_ev, 0);
-                }
-                if (wave_first || !others) {
-                    launch_idct_wave(wv[k], k, wave_stream[k]);
-                    launches++;
-                    wv[k].n_items = 0;
-                }
-            }
-        }
         const int n_k = (int)c->type_launches.size() + (int)c->special_launches.size();
         const bool fork = n_k > 1 && c->n_aux > 0;
         if (wn[0] > 0 || wn[1] > 0) {
@@ -1890,19 +1877,6 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 }
         }
         if (c->large_count > 0) launch_idct_large(f, blocks, c->h_blocks.data(), c->large_first, c->large_count, A, B, s, &launches);
-        // launched behind the small grids of the other types (special 8x8, 64-point, 128/256-edge): those were dispatched first
-        // and hold their few wave slots; these launches' 64-thread workgroups fill everything else
-        for (int k = 1; k >= 0; k--) {
-            if (!wave_stream[k]) continue;
-            if (wv[k].n_items > 0) {
-                launch_idct_wave(wv[k], k, wave_stream[k]);
-                launches++;
-            }
-            if (wave_stream[k] != s) {
-                (void)hipEventRecord(c->wave_join_ev[k], wave_stream[k]);
-                (void)hipStreamWaitEvent(s, c->wave_join_ev[k], 0);
-            }
-        }
     }
     // Frame.invertSubsampling (Frame.java:457, 681-723): horizontal doublings, then vertical ones, per channel
     float* curp[3] = {A[0], A[1], A[2]};
@@ -2026,7 +2000,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
 bool batchable(const jxl_ctx* c) {
     for (const auto& sl : c->special_launches)
         if (!sl.wg_items) return false;  // k_idct_special_batch takes workgroup items
-    return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && c->wave_segs.empty() && (c->p.stages & JXL_STAGE_IDCT);
+    return c->frame_open && !c->sub && c->large_count == 0 && c->llf_count == 0 && (c->p.stages & JXL_STAGE_IDCT);
 }
 }  // namespace
 

@@ -140,18 +140,6 @@ size_t wg3_lds_bytes(const Wg3Args& a);
 void launch_llf_wg3_batch(const Wg3Args* dev_args, int n_frames, int64_t max_llf, hipStream_t s);
 void launch_idct_wg3_batch(const Wg3Args* dev_args, int n_frames, bool big, int grid_x, size_t lds, hipStream_t s);
 
-// Argument block of the wave-per-item IDCT launch (k_idct_wave.hip): the METHOD_DCT varblocks of 8 to 32 points per side
-struct WaveArgs {
-    DevFrame f;
-    const DevBlock* blocks;
-    float *o0, *o1, *o2;
-    const int* items;  // 16-byte records {type (-1: hole), first_block, n_blocks, 0} in launch order (wave_item_table)
-    int n_items;
-};
-bool wave_handles(int type);
-// cls 0: 8x8, 16x16, 16x8, 8x16 (k_idct_wave_small); 1: 32x32, 32x8, 8x32, 32x16, 16x32 (k_idct_wave_big)
-void wave_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int cls, std::vector<int>& out);
-void launch_idct_wave(const WaveArgs& a, int cls, hipStream_t s);
 
 // ---- launchers (defined in the kernel TUs) ---------------------------------------------------
 // One launch per register class (0: every type up to 32x32, 1: the 64-point family), 256-thread workgroups.
@@ -220,14 +208,8 @@ struct FusedArgs {
     const int32_t* hf_mul;
     const int32_t* sharpness;
     int W, H, bw;
-    int ring_only;         // tile kernel: only the tiles that touch the frame-edge ring (the interior is k_restore_stream's)
-    int ring_tx, ring_ty;  // first tile column / row of the right / bottom border (filled by the launcher)
     RestoreParams p;
 };
-// k_restore_stream.hip: the interior of a frame (every pixel at least restore_stream_ring() away from the frame edges)
-int restore_stream_ring(const RestoreParams& p);
-bool restore_stream_covers(const FusedArgs& a);
-void launch_restore_stream(const FusedArgs& a, hipStream_t s);
 // false if the configuration is not covered by the fused kernel
 bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                              const int32_t* sharpness, const RestoreParams& p, FusedArgs& a);

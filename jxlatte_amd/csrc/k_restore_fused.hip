@@ -21,8 +21,6 @@ bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h
     a.W = w;
     a.H = h;
     a.bw = (w + 7) >> 3;
-    a.ring_only = 0;
-    a.ring_tx = a.ring_ty = 0;
     a.p = p;
     return true;
 }
@@ -44,11 +42,6 @@ bool launch_restore_fused(const float* const in[3], void* const out[3], int h, i
                           const int32_t* sharpness, const RestoreParams& p, hipStream_t s) {
     FusedArgs a;
     if (!fill_restore_fused_args(in, out, h, w, hf_mul, sharpness, p, a)) return false;
-    if (restore_stream_covers(a)) {
-        // interior: register-streaming kernel (k_restore_stream.hip); the ring along the frame edges: this file's tiles
-        launch_restore_stream(a, s);
-        a.ring_only = 1;
-    }
     const int sk = sink_kind_of(p);
     if (sk == SK_PLAIN) {
         // 4x1 patches on 512 threads everywhere: twice the waves per CU of 4x2 patches for the same LDS footprint. The

@@ -482,27 +482,7 @@ __device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
     // lines of the 62-wide output rows) then meet in the same L2. Speed only, never correctness.
     const int tiles_x = (W + G::OW - 1) / G::OW, tiles_y = (H + G::OH - 1) / G::OH;
     int ox, oy;
-    if (a.ring_only) {
-        // only the tiles that hold pixels of the frame-edge ring (the interior belongs to k_restore_stream): every tile of the
-        // top / bottom border rows, then the left / right border tiles of the rows between (see ring_tile_count)
-        const int nTB = a.ring_ty > 0 ? 1 + tiles_y - a.ring_ty : tiles_y;
-        const int nLR = a.ring_tx > 0 ? 1 + tiles_x - a.ring_tx : tiles_x;
-        const int idx = (int)blockIdx.x;
-        int tx, ty;
-        if (idx < tiles_x * nTB) {
-            const int j = idx / tiles_x;
-            tx = idx - j * tiles_x;
-            ty = a.ring_ty > 0 ? (j == 0 ? 0 : a.ring_ty + j - 1) : j;
-        } else {
-            const int i2 = idx - tiles_x * nTB;
-            const int row = i2 / nLR, k = i2 - row * nLR;
-            ty = row + 1;
-            tx = a.ring_tx > 0 ? (k == 0 ? 0 : a.ring_tx + k - 1) : k;
-            if (ty >= a.ring_ty) return;  // uniform per workgroup, before any barrier
-        }
-        ox = tx * G::OW;
-        oy = ty * G::OH;
-    } else {
+    {
         const int n_tiles = tiles_x * tiles_y;
         const int per_xcd = (n_tiles + 7) >> 3;
         const int tile = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
@@ -696,18 +676,6 @@ void launch_tph(const FusedArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int tiles_x = (a.W + G::OW - 1) / G::OW, tiles_y = (a.H + G::OH - 1) / G::OH;
-    if (a.ring_only) {
-        // tiles that intersect the ring of G::RT pixels along the frame edges
-        FusedArgs r = a;
-        r.ring_tx = (a.W - G::RT) / G::OW;
-        r.ring_ty = (a.H - G::RT) / G::OH;
-        const int nTB = r.ring_ty > 0 ? 1 + tiles_y - r.ring_ty : tiles_y;
-        const int nLR = r.ring_tx > 0 ? 1 + tiles_x - r.ring_tx : tiles_x;
-        const int mid = r.ring_ty > 0 ? r.ring_ty - 1 : 0;
-        const dim3 grid(tiles_x * nTB + mid * nLR);
-        hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, SK, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, r);
-        return;
-    }
     const int n_tiles = tiles_x * tiles_y;
     const dim3 grid(((n_tiles + 7) / 8) * 8);
     hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, SK, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, a);

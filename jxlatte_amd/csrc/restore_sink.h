@@ -1,5 +1,4 @@
-// Output sink shared by the fused restoration kernels (k_restore_fused.hip: LDS tiles, k_restore_stream.hip: register
-// streaming): OpsinInverseMatrix.invertXYB (OpsinInverseMatrix.java:105-142) + JXLImage.transferInPlace
+// Output sink of the fused restoration kernels (k_restore_fused*.hip): OpsinInverseMatrix.invertXYB (OpsinInverseMatrix.java:105-142) + JXLImage.transferInPlace
 // (JXLImage.java:244-258, TransferFunction.java:39-44,83-87) + ImageBuffer.castToInt0 (ImageBuffer.java:129-147) + the
 // global store of one pixel.
 #pragma once

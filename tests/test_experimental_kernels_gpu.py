@@ -1,7 +1,7 @@
-"""The two round-3 kernels that are kept behind environment switches (measured slower than the defaults):
-k_idct_wave (JXL_IDCT_WAVE=1) and k_restore_stream (JXL_RESTORE_STREAM=1). They stay under the same bit-exact parity bar as the
-product path: every frame below is decoded by a fresh process with the switch set (the library reads it once) and compared with
-the oracle bit for bit."""
+"""The launch-plan / item-order switches of the IDCT stage that DESIGN.md and profiles/r3_experiments.md name (each a path that was
+the default at some point) stay under the same bit-exact parity bar as the product path: every frame below is decoded by a fresh
+process with the switch set (the library reads it once) and compared with the oracle bit for bit. (The two round-3 kernels that
+lost -- k_idct_wave, k_restore_stream -- left the library in round 5: profiles/experiments/r5_removed_r3_kernels.diff.)"""
 import os
 import subprocess
 import sys
@@ -33,10 +33,10 @@ sys.exit(1 if bad else 0)
 """ % ROOT
 
 
-@pytest.mark.parametrize("switch", ["JXL_IDCT_WAVE", "JXL_RESTORE_STREAM", "JXL_WG3_LLF_IN_ITEM=0", "JXL_WG3_BALANCE=0", "JXL_WG3_BIG_FIRST=0",
+@pytest.mark.parametrize("switch", ["JXL_WG3_LLF_IN_ITEM=0", "JXL_WG3_BALANCE=0", "JXL_WG3_BIG_FIRST=0",
                                     "JXL_WG3_BIG_AFTER", "JXL_WG3_SPATIAL=0"])
 def test_switched_kernel_is_bit_exact(switch):
-    """the experimental kernels, and the launch-plan / item-order switches DESIGN.md and profiles/r3_experiments.md name (each a
+    """the launch-plan / item-order switches DESIGN.md and profiles/r3_experiments.md name (each a
     path that was the default at some point): same bits as the oracle"""
     env = dict(os.environ)
     name, _, val = switch.partition("=")
