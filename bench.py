@@ -48,7 +48,7 @@ def parse(argv=None):
     ap.add_argument("--input", default=os.path.join(ROOT, "tests", "golden", "samples", "bbb.jxl"),
                     help="--workload jxlfile: a VarDCT .jxl file parsed by the C++ front-end (real varblock statistics)")
     ap.add_argument("--frames-per-gpu", type=int, default=8)
-    ap.add_argument("--distinct-frames", type=int, default=4, help="distinct synthetic frames generated per rank (the rest reuse them)")
+    ap.add_argument("--distinct-frames", type=int, default=8, help="distinct synthetic frames generated per rank (the rest reuse them); default: every frame of the C5 share its own seed 1000 + i (SURVEY 8(d))")
     ap.add_argument("--mix", default="default")
     ap.add_argument("--stream-groups", type=int, default=0, help="experiment: the frames' contexts share G main streams (0: one per frame)")
     ap.add_argument("--size", default="", help="WxH override of the synthetic VarDCT frame size (diagnostics; named in config.workload)")
@@ -382,9 +382,9 @@ def main():
     # measured per-launch counters of this kernel (profiles/<round>_traffic.json, written by tools/profile_round.sh from the
     # rocprofv3 --pmc passes of this same command): HBM bytes and VALU wave-instructions. rocprofv3 cannot run inside
     # the bench; the figures are carried over only when workload and variant match, else null.
-    traffic, valu_insts, traffic_src = None, None, None
+    traffic, valu_insts, traffic_src, valu_all = None, None, None, None
     src_sha = kernel_source_sha()
-    for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if args.workload == "vardct4k" and epf_iters == 2 and args.mix == "default" and os.path.exists(tpath):
             try:
@@ -395,6 +395,7 @@ def main():
                     continue
                 traffic = int(tj["hbm_bytes_per_launch"])
                 valu_insts = tj.get("valu_wave_insts_per_launch")
+                valu_all = tj.get("valu_wave_insts_all_launches_per_frame")
                 traffic_src = "profiles/" + name
                 break
             except Exception:
@@ -420,6 +421,15 @@ def main():
         roofline.update({"valu_wave_insts_per_launch": int(valu_insts), "valu_insts_per_pixel": round(valu_insts * 64.0 / npx, 1),
                          "valu_achieved_Ginst_s": round(g, 1), "valu_peak_Ginst_s": VALU_PEAK_GINST,
                          "valu_frac": round(g / VALU_PEAK_GINST, 4)})
+    if valu_all:
+        # the bound of the PATH as it is built today: the wave-instructions of ALL launches of a frame at the issue peak
+        ceil_ms = valu_all / (VALU_PEAK_GINST * 1e9) * 1e3
+        per_frame_ms = ms_per_step / max(fpg, 1)
+        roofline.update({"valu_wave_insts_all_launches_per_frame": int(valu_all), "valu_ceiling_ms": round(ceil_ms, 4),
+                         "valu_frac_path": round(ceil_ms / per_frame_ms, 4) if per_frame_ms > 0 else None,
+                         "valu_frac_single_frame": round(ceil_ms / ms_all, 4) if ms_all > 0 else None,
+                         "valu_note": "valu_ceiling_ms = wave-instructions of every launch of one frame / 1228.8 G per s (1024 SIMDs x 1 per 2 "
+                                      "cycles x 2.4 GHz); valu_frac_path = that ceiling / the batch's time per frame"})
 
     cpu = None
     if not args.no_cpu_baseline and distinct:
@@ -472,14 +482,31 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_source_sha():
-    """sha256 over the sources of the dominant kernel (the stamp of profiles/rN_traffic.json)"""
+def _normalised_source(path):
+    """a source file without comments, blank lines and indentation: what the stamp of a profile hashes, so that a comment or a
+    re-wrapped line does not void the counters of an unchanged kernel (r4: a switch added to a hashed file six minutes after the
+    last profile pass cost the driver's line its traffic figure)"""
+    import re
+    txt = open(path, "r", encoding="utf-8", errors="replace").read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    out = []
+    for ln in txt.split("\n"):
+        ln = re.sub(r"//.*$", "", ln).strip()
+        if ln:
+            out.append(re.sub(r"\s+", " ", ln))
+    return "\n".join(out).encode()
+
+
+def kernel_source_sha(files=("k_restore_fused.hip", "restore_fused_body.h", "restore_sink.h", "jxl_fastpow.h")):
+    """sha256 over the normalised sources of the dominant kernel (the stamp of profiles/rN_traffic.json)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("k_restore_fused.hip", "restore_fused_body.h", "restore_sink.h", "jxl_fastpow.h"):
-        with open(os.path.join(ROOT, "jxlatte_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    for f in files:
+        h.update(_normalised_source(os.path.join(ROOT, "jxlatte_amd", "csrc", f)))
     return h.hexdigest()
+
+
+MODULAR_SOURCES = ("k_modular.hip", "k_modular_vh.hip", "modular_tend.h")
 
 
 def gather_legs(args, torch, dist, shard, lib, ctxs, frames, step, sync_all, n_frames, rank, world, H, W):
@@ -828,6 +855,15 @@ def bench_modular(args, rank, world, local_rank, torch, dist):
     value = npx * fpg * world * args.steps / elapsed / 1e6
     bytes_img = 24.0 * npx
     gbs = bytes_img * fpg * args.steps / elapsed / 1e9
+    # HBM bytes of one plan from the PMC passes of tools/profile_modular.sh (carried while the kernels' sources hash to what was profiled)
+    mtraffic, mtraffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r5_modular_traffic.json")))
+        if tj.get("kernel_source_sha256") == kernel_source_sha(MODULAR_SOURCES) and args.workload in tj.get("plans", {}):
+            mtraffic = int(tj["plans"][args.workload]["hbm_bytes_per_plan"])
+            mtraffic_src = "profiles/r5_modular_traffic.json"
+    except Exception:
+        pass
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import pyoracle as orc
@@ -848,8 +884,10 @@ def bench_modular(args, rank, world, local_rank, torch, dist):
         "config": {"workload": "%s: %d images per GPU, %d squeeze steps" % (args.workload, fpg, len(mod["sp"])),
                    "launches": ctxs[0].lib.jxl_modular_last_launch_count(ctxs[0].h)},
         "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "note": "whole step list (24 B/px algorithmic over the elapsed time of all steps); segmented walk of the serial squeeze recurrence: 64-pair segments with a 16-pair warm-up, verified and redone serially where a boundary state differs (DESIGN.md 4.3)"},
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": mtraffic, "traffic_source": mtraffic_src,
+                     "algorithmic_bytes_per_image": int(bytes_img),
+                     "note": "whole step list (24 B/px algorithmic over the elapsed time of all steps); V + H step of a level as one launch "
+                             "(V output in LDS only), guessed chain states verified and the plan redone in order where one differs (DESIGN.md 4.3)"},
         "cpu_baseline": cpu,
     })
 

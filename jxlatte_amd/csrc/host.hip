@@ -3262,6 +3262,9 @@ jxl_status mod_settle(jxl_ctx* c) {
     *c->mod_flag_host = 0;
     HIP_TRY(c, hipMemset(c->mod_flag.p, 0, sizeof(int32_t)));
     c->mod_redos++;
+    // a plan whose data trip the fused kernel (chains that do not forget their start, or samples outside the short tendency form's
+    // range guard) would pay for two runs every time: from here on this plan runs its one-step launches (still checked in flight)
+    c->mod_ops_fused.clear();
     const jxl_status st = run_modular_plan(c, 0);
     if (st) return st;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
