@@ -2866,6 +2866,13 @@ bool make_vh(jxl_ctx* c, const SqueezeBatch& v, const SqueezeBatch& h, VHBatch& 
     while (seg > 32 && tiles_with(seg) < want) seg >>= 1;
     if (seg == 32 && tiles_with(32) < small) seg = 16;
     if (seg_env >= 16) seg = (seg_env + 15) & ~15;
+    // chunk width: the wide form (128-byte input pieces, 256-byte output pieces, 1.5 x instead of 2 x redundant V pairs, 9 waves
+    // per CU) where the step is bound by the memory system, i.e. where it got long segments; JXL_VH_CW forces one
+    const int cw_env = getenv("JXL_VH_CW") ? atoi(getenv("JXL_VH_CW")) : 0;
+    int cw = seg >= 128 ? 32 : 16;
+    if (cw_env == 16 || cw_env == 32) cw = cw_env;
+    if (cw == 32) seg = (seg + 31) & ~31;
+    out.cw = cw;
     int tile0 = 0;
     for (int i = 0; i < v.n; i++) {
         VHDesc& d = out.d[i];

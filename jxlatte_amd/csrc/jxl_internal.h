@@ -285,7 +285,7 @@ struct VHDesc {
     const int32_t* hb;  // H residuals [ah + rh][rw]
     int32_t* o;         // output      [ah + rh][w + rw]
     int w, ah, rh, rw;  // rh >= 1, rw >= 1; ah - rh and w - rw are 0 or 1
-    int seg;            // H pairs per segment (a multiple of 16)
+    int seg;            // H pairs per segment (a multiple of VHBatch::cw)
     int nseg, nstripe;  // ceil(rw / seg), ceil((ah + rh) / 64)
     int tile0;          // index of this channel's first tile in the launch (tiles: [stripe][segment])
     int32_t *side_h, *tail_h;  // [nseg][ah + rh]
@@ -293,6 +293,7 @@ struct VHDesc {
 };
 struct VHBatch {
     int n, n_tiles;
+    int cw;         // H pairs per chunk: 16 or 32 (the kernel instantiation; VHDesc::seg is a multiple of it)
     VHDesc d[8];
     int32_t* flag;  // report a mismatch (atomicOr 1); never null
     int n_chk;      // segment-boundary arrays of an EARLIER step, checked in this launch's prologue

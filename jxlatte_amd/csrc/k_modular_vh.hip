@@ -4,15 +4,18 @@
 // pair reads avg (1/4) + V residuals (1/4) + H residuals (1/2) and writes the level (1) = 2 x its samples, against 3 x for two
 // launches.
 //
-// One wave = one tile = 64 output rows (32 V pairs: a "stripe") x one H segment, walked left to right in chunks of 16 H pairs
-// (= 32 output columns = one 128-byte line per row). Per chunk:
-//   V pass   lane (q, j) = (quarter of the stripe, column): 16 V-output columns x 4 quarters of 8 pairs, each quarter started
-//            8 pairs early from a guessed state (the recurrence forgets its start within a few pairs: jxl_internal.h).
-//            Inputs straight from global memory (row pieces of 64 bytes), outputs into the LDS image A[row][column].
-//   H pass   lane = row: reads its row of A and of the H residuals R (staged through LDS by coalesced 16-byte loads), walks 16
-//            pairs serially from the chain state it carries in a register from chunk to chunk, and puts the 32 outputs back
-//            into its own LDS row.
-//   output   whole 128-byte row pieces leave LDS as 16-byte stores.
+// One wave = one tile = 64 output rows (32 V pairs: a "stripe") x one H segment, walked left to right in chunks of CW H pairs
+// (CW = 16: 32 output columns = one 128-byte line per row; CW = 32: two). Per chunk:
+//   V pass   lane (q, j) = (part of the stripe, column): CW V-output columns x 64 / CW parts of 32 CW / 64 pairs, each part
+//            started 8 pairs early from a guessed state (the recurrence forgets its start within a few pairs: jxl_internal.h).
+//            Inputs straight from global memory (row pieces of 4 CW bytes), outputs into the LDS image A[row][column].
+//   H pass   lane = row: reads its row of A and of the H residuals R (staged through LDS by coalesced 16-byte loads), walks CW
+//            pairs serially from the chain state it carries in a register from chunk to chunk, and leaves every pair's two
+//            outputs in the two LDS slots the pair has just consumed.
+//   output   whole row pieces (8 CW bytes) leave LDS as 16-byte stores.
+// CW = 32 (r5, the big steps): 128-byte input pieces and 256-byte output pieces -- the access shape of CW = 16 tops out at
+// ~3.8 TB/s of HBM traffic on this part, CW = 32 at ~4.7 (tools/ubench/vh_pattern.hip) -- and 1.5 x instead of 2 x redundant V
+// pairs (two halves of 16 + 8 instead of four quarters of 8 + 8), for 16.6 KB of LDS per wave instead of 8.4.
 // The V pass of a chunk produces columns c0+1 .. c0+16 (the H pair at column c needs column c + 1 as its `next average`); column
 // c0 itself is the last column of the previous chunk and is handed on in a register. Output stores and H-residual loads stay
 // line-aligned; only the V input pieces are shifted by one sample.
@@ -25,8 +28,8 @@
 // The compact side / tail arrays are compared in the prologue of a LATER launch (SqueezeCheck) or by k_squeeze_check; any
 // mismatch sets VHBatch::flag and the host runs the plan again with the one-step kernels in order (host.hip, mod_settle).
 //
-// LDS: 64 rows x 35 dwords = 8960 B per wave (A: columns 0..16, R: 17..32; the 32 outputs of a row overwrite its own A / R
-// samples after the lane has read them) -> 18 waves per CU. The row stride is odd: lane = row accesses are conflict-free.
+// LDS: 64 rows x (2 CW + 1) dwords per wave (A: slots 0..CW, R: CW+1..2CW; pair i leaves its outputs in A[i] and R[i]): 8448 B
+// (19 waves per CU) for CW = 16, 16640 B (9) for CW = 32. The row stride is odd: lane = row accesses are conflict-free.
 #include "jxl_internal.h"
 #include "modular_tend.h"
 #include <cstdlib>
@@ -35,24 +38,33 @@
 namespace jxl {
 namespace {
 
-#ifdef JXL_VH_ABL  // timing-only ablations (experiment builds): 1 = no loads, 2 = no stores, 4 = no walks (set per launch from the environment)
-__device__ int g_vh_abl;
-#define VH_ABL(bit) (g_vh_abl & (bit))
-#else
-#define VH_ABL(bit) 0
-#endif
-
-constexpr int VH_CW = 16;    // H pairs per chunk
-constexpr int VH_LD = 35;    // LDS row stride in dwords
 constexpr int VH_ROWS = 64;  // output rows per tile
-constexpr int VH_R0 = 17;    // first H-residual column of an LDS row
+constexpr int VH_WP = 8;     // warm-up pairs in front of every part of a V pass
 
-// orders this wave's LDS traffic (one wave per workgroup: no s_barrier needed, the LDS queue of a wave is in order)
-__device__ __forceinline__ void lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+// geometry of the two chunk widths
+template <int CW>
+struct VHG {
+    static constexpr int NQ = 64 / CW;      // parts of the stripe in a V pass (lane = (part, column))
+    static constexpr int KP = 32 / NQ;      // pairs a part keeps
+#ifdef JXL_VH_LDPAD
+    static constexpr int LD = 2 * CW + 1 + JXL_VH_LDPAD;
+#else
+    static constexpr int LD = 2 * CW + 1;   // LDS row stride in dwords
+#endif
+    static constexpr int R0 = CW + 1;       // first H-residual slot of an LDS row
+    static constexpr int HL = CW / 4;       // lanes per row of a 16-byte H-residual load
+    static constexpr int HN = 64 / (64 / HL);  // such loads per chunk ( = HL )
+    static constexpr int SL = CW / 2;       // lanes per row of a 16-byte output store
+    static constexpr int SN = SL;           // such stores per chunk
+};
+
+// Orders this wave's LDS traffic: what other LANES wrote before it is visible to every read after it. One wave per workgroup, so no
+// s_barrier is needed -- the LDS queue of a wave is in order -- but the COMPILER must not move an LDS access across it either, and a
+// workgroup-scope fence does not promise that here: with a flat workgroup size of 64 the compiler may drop it (one wave: nothing
+// to synchronise with, it reasons), after which a lane's reads of slots other lanes wrote are free to float above those writes.
+// The first r5 build did exactly that after a refactoring changed the schedule: a handful of samples per image read stale
+// LDS, differently from run to run. An asm statement that clobbers memory is a barrier the optimiser cannot reason away.
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Plane accesses go through buffer descriptors: 32-bit offsets (a uniform row term in an SGPR, the lane's term in one VGPR that
 // is the same for every row of a pass) and the hardware range check -- a row above the first or below the last reads as 0 and a
@@ -66,97 +78,106 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t vh_rsrc(const void* p, int64_t
 }
 constexpr uint32_t kVhOob = 0xFFFFFFF0u;  // beyond every plane (< 2^30 samples): such a store is dropped
 
-// The inputs of one V pass as they are LOADED: every lane fetches the rows of its own quarter only (8 averages, 8 residuals).
-// The 8 warm-up pairs in front of a quarter are the previous quarter's own rows and come from lane - 16 by ds_bpermute; only
-// quarter 0 loads its warm-up rows itself (they lie above the stripe), and quarter 3 the one average row below it. (r5, first
-// form: every lane loaded all 17 + 16 rows of its walk, so a wave requested each row piece twice within a few instructions --
-// the L1 stalls on a second request to a line whose miss is still pending: TCP_PENDING_STALL_CYCLES was 70 % of the launch.)
+// The inputs of one V pass as they are LOADED: every lane fetches the rows of its own part only (KP averages, KP residuals).
+// The 8 warm-up pairs in front of a part are the previous part's last own rows and come from lane - CW by ds_bpermute; only
+// part 0 loads its warm-up rows itself (they lie above the stripe), and the last part the one average row below it. (r5, first
+// form: every lane loaded all rows of its walk, so a wave requested each row piece twice within a few instructions.)
+template <int CW>
 struct VLoad {
-    int32_t a[8], r[8];    // own rows: pairs 32 st + 8 q + i
-    int32_t wa[8], wr[8];  // quarter 0: pairs 32 st - 8 + i
-    int32_t nx;            // quarter 3: average row 32 st + 32
+    int32_t a[VHG<CW>::KP], r[VHG<CW>::KP];  // own rows: pairs 32 st + KP q + i
+    int32_t wa[VH_WP], wr[VH_WP];            // part 0: pairs 32 st - 8 + i
+    int32_t nx;                              // last part: average row 32 st + 32
+    __device__ __forceinline__ void clear_edges() {
+        nx = 0;
+#pragma unroll
+        for (int i = 0; i < VH_WP; i++) wa[i] = wr[i] = 0;
+    }
 };
-// inside = every row and column the pass touches exists (st >= 1, 32 st + 33 <= ah, 32 st + 32 <= rh, cfirst + 16 <= w): the
+// inside = every row and column the pass touches exists (st >= 1, 32 st + 33 <= ah, 32 st + 32 <= rh, cfirst + CW <= w): the
 // row term rides in the SGPR offset. Otherwise the whole offset sits in the VGPR (an SGPR offset is not range-checked): rows
 // above the plane wrap to huge offsets and read 0 like the rows below it.
-__device__ __forceinline__ void vh_v_load(const VHDesc& d, const VHRsrc& rs, int st, int cfirst, bool inside, VLoad& in) {
-    const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+template <int CW>
+__device__ __forceinline__ void vh_v_load(const VHDesc& d, const VHRsrc& rs, int st, int cfirst, bool inside, VLoad<CW>& in) {
+    using G = VHG<CW>;
+    const int lane = threadIdx.x, q = lane / CW, j = lane % CW;
     const int w = d.w;
-    // the row pitch as a value the compiler cannot see through: it would otherwise keep the 17 row offsets i * pitch of a pass in
+    // the row pitch as a value the compiler cannot see through: it would otherwise keep the row offsets i * pitch of a pass in
     // registers across the whole chunk loop (loop-invariant); formed by one add per load they need one
     int w4 = w * 4;
     asm volatile("" : "+s"(w4));
     if (inside) {
-        const int voff = (8 * q * w + j) * 4;
+        const int voff = (G::KP * q * w + j) * 4;
         const int soff = (32 * st * w + cfirst) * 4;
         int so = soff;
 #pragma unroll
-        for (int i = 0; i < 8; i++, so += w4) {
+        for (int i = 0; i < G::KP; i++, so += w4) {
             in.a[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.va, voff, so, 0);
             in.r[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.vb, voff, so, 0);
         }
-        if (q == 3) in.nx = __builtin_amdgcn_raw_buffer_load_b32(rs.va, voff, so, 0);
+        if (q == G::NQ - 1) in.nx = __builtin_amdgcn_raw_buffer_load_b32(rs.va, voff, so, 0);
         if (q == 0) {
-            so = soff - 8 * w4;
+            so = soff - VH_WP * w4;
 #pragma unroll
-            for (int i = 0; i < 8; i++, so += w4) {
+            for (int i = 0; i < VH_WP; i++, so += w4) {
                 in.wa[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.va, voff, so, 0);
                 in.wr[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.vb, voff, so, 0);
             }
         }
     } else {
-        int vo = ((32 * st + 8 * q) * w + min(cfirst + j, w - 1)) * 4;
-        const int vo0 = vo - 8 * w4;
+        int vo = ((32 * st + G::KP * q) * w + min(cfirst + j, w - 1)) * 4;
+        const int vo0 = vo - VH_WP * w4;
 #pragma unroll
-        for (int i = 0; i < 8; i++, vo += w4) {
+        for (int i = 0; i < G::KP; i++, vo += w4) {
             in.a[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.va, vo, 0, 0);
             in.r[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.vb, vo, 0, 0);
         }
-        if (q == 3) in.nx = __builtin_amdgcn_raw_buffer_load_b32(rs.va, vo, 0, 0);
+        if (q == G::NQ - 1) in.nx = __builtin_amdgcn_raw_buffer_load_b32(rs.va, vo, 0, 0);
         if (q == 0) {
             vo = vo0;
 #pragma unroll
-            for (int i = 0; i < 8; i++, vo += w4) {
+            for (int i = 0; i < VH_WP; i++, vo += w4) {
                 in.wa[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.va, vo, 0, 0);
                 in.wr[i] = __builtin_amdgcn_raw_buffer_load_b32(rs.vb, vo, 0, 0);
             }
         }
     }
 }
-// One V pass: V-output columns cfirst + j (j = lane & 15, j < nc) of stripe st into LDS column slot0 + j. The walk covers pairs
-// ybase .. ybase + 15 (ybase = 32 st + 8 q - 8): its first 8 pairs -- the warm-up -- take their inputs from lane - 16 (the
-// previous quarter's own rows) as they go, the last 8 are the lane's own loads.
-// EDGE = false: st >= 1, every row the pass touches exists (32 st + 33 <= ah, 32 st + 32 <= rh), all 16 columns exist.
+// One V pass: V-output columns cfirst + j (j = lane % CW, j < nc) of stripe st into LDS slot slot0 + j. The walk of part q covers
+// pairs ybase .. ybase + 8 + KP - 1 (ybase = 32 st + KP q - 8): its first 8 pairs -- the warm-up -- take their inputs from lane -
+// CW (the previous part's own rows) as they go, the others are the lane's own loads.
+// EDGE = false: st >= 1, every row the pass touches exists (32 st + 33 <= ah, 32 st + 32 <= rh), all CW columns exist.
 // Only the short form of tendency() lives in this kernel (modular_tend.h): samples outside its range guard are REPORTED like a
 // mismatching boundary (the guard rides along the walk; what a violating walk stored is overwritten when the plan runs again
 // with the one-step kernels, which carry the reference's long form). Both forms inlined per pass doubled the loop's code and
 // spilled registers -- and a scratch reload makes the compiler wait for every outstanding load and store.
-template <bool EDGE>
-__device__ __forceinline__ void vh_v_pass(const VHDesc& d, const VLoad& ld, int st, int cfirst, int nc, int slot0, bool store_state,
+template <int CW, bool EDGE>
+__device__ __forceinline__ void vh_v_pass(const VHDesc& d, const VLoad<CW>& ld, int st, int cfirst, int nc, int slot0, bool store_state,
                                           int32_t* lds, bool& bad) {
-    const int lane = threadIdx.x, q = lane >> 4, j = lane & 15;
+    using G = VHG<CW>;
+    constexpr int KP = G::KP, NS = VH_WP + KP;
+    const int lane = threadIdx.x, q = lane / CW, j = lane % CW;
     const int w = d.w;
-    const int ybase = 32 * st + 8 * q - 8;
+    const int ybase = 32 * st + KP * q - VH_WP;
     const int col = min(cfirst + j, w - 1);
     const bool colok = !EDGE || (j < nc && cfirst + j < w);
     const bool wr = !EDGE || j < nc;
-    int32_t* p = lds + (16 * q) * VH_LD + slot0 + j;
-    auto warm_a = [&](int i) { const int32_t t = __shfl_up(ld.a[i], 16); return q == 0 ? ld.wa[i] : t; };
-    auto warm_r = [&](int i) { const int32_t t = __shfl_up(ld.r[i], 16); return q == 0 ? ld.wr[i] : t; };
+    int32_t* p = lds + (2 * KP * q) * G::LD + slot0 + j;
+    auto warm_a = [&](int i) { const int32_t t = __shfl_up(ld.a[KP - VH_WP + i], CW); return q == 0 ? ld.wa[i] : t; };
+    auto warm_r = [&](int i) { const int32_t t = __shfl_up(ld.r[KP - VH_WP + i], CW); return q == 0 ? ld.wr[i] : t; };
     int32_t a = warm_a(0);
     int32_t top = a, side = 0;
     SqueezeRange rg;
     rg.init(a);
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < NS; i++) {
         int32_t nx, r;
-        if (i < 7) nx = warm_a(i + 1);
-        else if (i < 15) nx = ld.a[i - 7];
+        if (i < VH_WP - 1) nx = warm_a(i + 1);
+        else if (i < NS - 1) nx = ld.a[i - (VH_WP - 1)];
         else {
-            const int32_t t = __shfl_down(ld.a[0], 16);
-            nx = q == 3 ? ld.nx : t;
+            const int32_t t = __shfl_down(ld.a[0], CW);
+            nx = q == G::NQ - 1 ? ld.nx : t;
         }
-        r = i < 8 ? warm_r(i) : ld.r[i - 8];
+        r = i < VH_WP ? warm_r(i) : ld.r[i - VH_WP];
         rg.add(nx, r);
         int32_t f, s;
         if (!EDGE) {
@@ -169,57 +190,62 @@ __device__ __forceinline__ void vh_v_pass(const VHDesc& d, const VLoad& ld, int 
             squeeze_pair_n(top, tend_n_pre(a, nxe, r), f, s);
             if (y >= 0 && y < d.rh) top = s;
         }
-        if (i == 7) side = top;
-        if (i >= 8 && wr) {
-            p[(2 * (i - 8)) * VH_LD] = f;
-            p[(2 * (i - 8) + 1) * VH_LD] = s;
+        if (i == VH_WP - 1) side = top;
+        if (i >= VH_WP && wr) {
+            p[(2 * (i - VH_WP)) * G::LD] = f;
+            p[(2 * (i - VH_WP) + 1) * G::LD] = s;
         }
         a = nx;
     }
     if (!rg.ok(0)) bad = true;
     if (EDGE && d.ah > d.rh) {  // odd height: the last row is the last average row (ModularChannel.java:409-411)
         const int yl = 2 * d.rh - VH_ROWS * st;
-        if (yl >= 0 && yl < VH_ROWS && q == 0 && colok) lds[yl * VH_LD + slot0 + j] = d.va[(int64_t)d.rh * w + col];
+        if (yl >= 0 && yl < VH_ROWS && q == 0 && colok) lds[yl * G::LD + slot0 + j] = d.va[(int64_t)d.rh * w + col];
     }
-    // the previous quarter's last output is what this quarter's warm-up should have arrived at
-    const int32_t prev_top = __shfl_up(top, 16);
-    const bool qlive = !EDGE || (colok && 32 * st + 8 * q < d.rh);
+    // the previous part's last output is what this part's warm-up should have arrived at
+    const int32_t prev_top = __shfl_up(top, CW);
+    const bool qlive = !EDGE || (colok && 32 * st + KP * q < d.rh);
     if (q >= 1 && qlive && side != prev_top) bad = true;
     if (store_state && colok) {
         const int nsv = (d.rh + 31) >> 5;  // stripes that hold V pairs
         if (q == 0 && st >= 1 && st < nsv) d.side_v[(int64_t)st * w + col] = side;
-        if (q == 3 && st + 1 < nsv) d.tail_v[(int64_t)st * w + col] = top;
+        if (q == G::NQ - 1 && st + 1 < nsv) d.tail_v[(int64_t)st * w + col] = top;
     }
 }
 
-// H residuals of pairs c0 .. c0+15, rows of the stripe -> registers (coalesced 16-byte loads: lane = (row, quarter of the row
-// piece)) -> LDS columns 17..32. Rows below the plane read as 0; columns beyond the row's end read the next row's samples,
-// which no pair that exists ever uses.
+// H residuals of pairs c0 .. c0 + CW - 1, rows of the stripe -> registers (coalesced 16-byte loads: lane = (row, piece of the row
+// piece)) -> LDS slots R0 .. R0 + CW - 1. Rows below the plane read as 0; columns beyond the row's end read the next row's
+// samples, which no pair that exists ever uses.
+template <int CW>
 struct HIn {
-    i32x4 v[4];
+    i32x4 v[VHG<CW>::HN];
 };
-__device__ __forceinline__ void vh_h_load(const VHDesc& d, const VHRsrc& rs, int st, int c0, bool inside, HIn& in) {
-    const int lane = threadIdx.x, pc = lane & 3;
-    const int voff = ((lane >> 2) * d.rw + 4 * pc) * 4;
-    int rw64 = 16 * d.rw * 4;
-    asm volatile("" : "+s"(rw64));  // (as in vh_v_load: one add per load instead of four offsets held across the chunk loop)
+template <int CW>
+__device__ __forceinline__ void vh_h_load(const VHDesc& d, const VHRsrc& rs, int st, int c0, bool inside, HIn<CW>& in) {
+    using G = VHG<CW>;
+    const int lane = threadIdx.x, pc = lane % G::HL;
+    const int voff = ((lane / G::HL) * d.rw + 4 * pc) * 4;
+    int rstep = (64 / G::HL) * d.rw * 4;
+    asm volatile("" : "+s"(rstep));  // (as in vh_v_load: one add per load instead of the offsets held across the chunk loop)
     if (inside) {
         int so = (VH_ROWS * st * d.rw + c0) * 4;
 #pragma unroll
-        for (int ps = 0; ps < 4; ps++, so += rw64) in.v[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs.hb, voff, so, 0);
+        for (int ps = 0; ps < G::HN; ps++, so += rstep) in.v[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs.hb, voff, so, 0);
     } else {  // rows below the plane: the whole offset in the VGPR, where the range check sees it
         int vo = voff + (VH_ROWS * st * d.rw + c0) * 4;
 #pragma unroll
-        for (int ps = 0; ps < 4; ps++, vo += rw64) in.v[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs.hb, vo, 0, 0);
+        for (int ps = 0; ps < G::HN; ps++, vo += rstep) in.v[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs.hb, vo, 0, 0);
     }
 }
-__device__ __forceinline__ void vh_h_to_lds(const HIn& in, int32_t* lds) {
-    const int lane = threadIdx.x, pc = lane & 3;
+template <int CW>
+__device__ __forceinline__ void vh_h_to_lds(const HIn<CW>& in, int32_t* lds) {
+    using G = VHG<CW>;
+    const int lane = threadIdx.x, pc = lane % G::HL;
 #pragma unroll
-    for (int ps = 0; ps < 4; ps++) {
-        const int rr = 16 * ps + (lane >> 2);
+    for (int ps = 0; ps < G::HN; ps++) {
+        const int rr = (64 / G::HL) * ps + lane / G::HL;
 #pragma unroll
-        for (int e = 0; e < 4; e++) lds[rr * VH_LD + VH_R0 + 4 * pc + e] = in.v[ps][e];
+        for (int e = 0; e < 4; e++) lds[rr * G::LD + G::R0 + 4 * pc + e] = in.v[ps][e];
     }
 }
 
@@ -227,18 +253,19 @@ __device__ __forceinline__ void vh_h_to_lds(const HIn& in, int32_t* lds) {
 // (EDGE only); extra: the odd last output column (a copy of V-output column rw) falls into this chunk at pair index npairs.
 // The row's samples are read from LDS as the walk reaches them; pair i leaves its two outputs in the two slots it has just
 // consumed (its average A[i] -- slot 0 is spare -- and its residual R[i]): nothing of the row has to sit in registers.
-template <bool EDGE>
+template <int CW, bool EDGE>
 __device__ __forceinline__ void vh_h_pass(const VHDesc& d, int c0, bool warm, bool first_true, int npairs, bool extra, int32_t* lds,
                                           int32_t a0, int32_t& left, int32_t& carry, bool& bad) {
-    int32_t* row = lds + threadIdx.x * VH_LD;
+    using G = VHG<CW>;
+    int32_t* row = lds + threadIdx.x * G::LD;
     int32_t a = warm ? row[1] : a0;
     if (first_true) left = a;  // the row's first pair uses its own average (ModularChannel.java:370)
     SqueezeRange rg;
     rg.init(a);
     if (!rg.ok(left)) bad = true;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int32_t nx = row[i + 1], r = row[VH_R0 + i];
+    for (int i = 0; i < CW; i++) {
+        const int32_t nx = row[i + 1], r = row[G::R0 + i];
         rg.add(nx, r);
         if (i == 1 && warm) left = a;  // the warm-up starts at pair c0 + 1 from the same guess
         int32_t f, s;
@@ -253,7 +280,7 @@ __device__ __forceinline__ void vh_h_pass(const VHDesc& d, int c0, bool warm, bo
         }
         if (!warm) {
             row[i] = f;
-            row[VH_R0 + i] = s;
+            row[G::R0 + i] = s;
         }
         a = nx;
     }
@@ -261,25 +288,33 @@ __device__ __forceinline__ void vh_h_pass(const VHDesc& d, int c0, bool warm, bo
     if (!rg.ok(0)) bad = true;
 }
 
-// the chunk's 64 x 32 outputs: LDS rows -> global, 16 bytes per lane, whole 128-byte row pieces
-template <bool EDGE>
+// the chunk's 64 x 2 CW outputs: LDS rows -> global, 16 bytes per lane, whole row pieces
+template <int CW, bool EDGE>
 __device__ __forceinline__ void vh_store(const VHDesc& d, const VHRsrc& rs, int st, int c0, int ncols, const int32_t* lds) {
-    const int lane = threadIdx.x, pc = lane & 7;
+    using G = VHG<CW>;
+    const int lane = threadIdx.x, pc = lane % G::SL;
     const int ow = d.w + d.rw;
-    const int voff = ((lane >> 3) * ow + 4 * pc) * 4;
-    int ow32 = 8 * ow * 4;
-    asm volatile("" : "+s"(ow32));
+    const int voff = ((lane / G::SL) * ow + 4 * pc) * 4;
+    int rstep = (64 / G::SL) * ow * 4;
+    asm volatile("" : "+s"(rstep));
     int so = (VH_ROWS * st * ow + 2 * c0) * 4;
-    const int32_t* src = lds + (lane >> 3) * VH_LD + 2 * pc;  // outputs 4 pc .. 4 pc + 3 = pairs 2 pc, 2 pc + 1: slots A[i] and R[i]
+    const int32_t* src = lds + (lane / G::SL) * G::LD + 2 * pc;  // outputs 4 pc .. 4 pc + 3 = pairs 2 pc, 2 pc + 1: slots A[i] and R[i]
 #pragma unroll
-    for (int ps = 0; ps < 8; ps++, so += ow32) {
+    for (int ps = 0; ps < G::SN; ps++, so += rstep) {
+        const int32_t* sp = src + (64 / G::SL) * ps * G::LD;
         i32x4 v;
-        v[0] = src[8 * ps * VH_LD];
-        v[1] = src[8 * ps * VH_LD + VH_R0];
-        v[2] = src[8 * ps * VH_LD + 1];
-        v[3] = src[8 * ps * VH_LD + VH_R0 + 1];
+        v[0] = sp[0];
+        v[1] = sp[G::R0];
+        v[2] = sp[1];
+        v[3] = sp[G::R0 + 1];
         if (!EDGE) {
             __builtin_amdgcn_raw_buffer_store_b128(v, rs.o, voff, so, 0);
+            // gfx950: a 16-byte store still reads its data registers for a few cycles after it has issued, and a VALU write of
+            // one of them in that window reaches memory in some lanes (observed: the last four lanes of every row of 16, one of
+            // the four dwords, differently from run to run). hipcc pads that hazard only for stores WITHOUT a register in the
+            // soffset field (its rule for older parts); this one has one, and the register allocator recycles v[2..3] of one
+            // store as v[0..1] of the next. Four wait states by hand (two were enough in every run).
+            asm volatile("s_nop 3");
         } else {  // rows below the plane are dropped by the range check (whole offset in the VGPR); columns beyond the chunk's last one must not be written
 #pragma unroll
             for (int e = 0; e < 4; e++) __builtin_amdgcn_raw_buffer_store_b32(v[e], rs.o, 4 * pc + e < ncols ? voff + so + 4 * e : (int)kVhOob, 0, 0);
@@ -303,8 +338,9 @@ __device__ __forceinline__ void squeeze_check_slice(const SqueezeCheck* chk, int
     if (__builtin_expect(__any(mism), 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-__global__ __launch_bounds__(64, 3) void k_inv_vh(const VHBatch bt) {
-    __shared__ int32_t lds[VH_ROWS * VH_LD];
+template <int CW>
+__device__ __forceinline__ void vh_body(const VHBatch& bt, int32_t* lds) {
+    using G = VHG<CW>;
     squeeze_check_slice(bt.chk, bt.n_chk, bt.flag);
     // consecutive workgroup ids go to different XCDs: give every XCD a contiguous run of tiles (neighbouring tiles share their
     // warm-up rows / columns, and an XCD has its own L2)
@@ -319,72 +355,78 @@ __global__ __launch_bounds__(64, 3) void k_inv_vh(const VHBatch bt) {
     const int st = local / d.nseg, sg = local - st * d.nseg;
     const int htot = d.ah + d.rh;
     const int xb = sg * d.seg, xe = min(d.rw, xb + d.seg);
-    const int xs = sg > 0 ? xb - VH_CW : 0;
+    const int xs = sg > 0 ? xb - CW : 0;
     const bool extra = sg == d.nseg - 1 && d.w > d.rw;  // the odd last output column belongs to the last segment
-    const int nck = (xe + (extra ? 1 : 0) - xs + VH_CW - 1) / VH_CW;
+    const int nck = (xe + (extra ? 1 : 0) - xs + CW - 1) / CW;
     const bool stripe_inside = st >= 1 && 32 * st + 33 <= d.ah && 32 * st + 32 <= d.rh && VH_ROWS * st + VH_ROWS <= htot;
     VHRsrc rs;
-    rs.va = vh_rsrc(d.va, VH_ABL(1) ? 0 : (int64_t)d.ah * d.w);
-    rs.vb = vh_rsrc(d.vb, VH_ABL(1) ? 0 : (int64_t)d.rh * d.w);
-    rs.hb = vh_rsrc(d.hb, VH_ABL(1) ? 0 : (int64_t)htot * d.rw);
-    rs.o = vh_rsrc(d.o, VH_ABL(2) ? 0 : (int64_t)htot * (d.w + d.rw));
+    rs.va = vh_rsrc(d.va, (int64_t)d.ah * d.w);
+    rs.vb = vh_rsrc(d.vb, (int64_t)d.rh * d.w);
+    rs.hb = vh_rsrc(d.hb, (int64_t)htot * d.rw);
+    rs.o = vh_rsrc(d.o, (int64_t)htot * (d.w + d.rw));
     int32_t left = 0, carry = 0;
     bool bad = false;
     const int grow = VH_ROWS * st + threadIdx.x;
     // software pipeline: the loads of chunk k + 1 are issued between the V pass and the H pass of chunk k and land while the
     // H pass and the output stores run
-    auto inside = [&](int c0) { return stripe_inside && c0 + VH_CW < d.w && c0 + VH_CW <= xe; };
-    VLoad vld;
-    HIn hin;
-    vld.nx = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) vld.wa[i] = vld.wr[i] = 0;
-    vh_v_load(d, rs, st, xs + 1, inside(xs), vld);
-    vh_h_load(d, rs, st, xs, inside(xs), hin);
+    auto inside = [&](int c0) { return stripe_inside && c0 + CW < d.w && c0 + CW <= xe; };
+    VLoad<CW> vld;
+    HIn<CW> hin;
+    vld.clear_edges();
+    vh_v_load<CW>(d, rs, st, xs + 1, inside(xs), vld);
+    vh_h_load<CW>(d, rs, st, xs, inside(xs), hin);
     if (sg == 0) {  // column 0 has no chunk to its left that would have produced it
-        VLoad l0;
-        l0.nx = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) l0.wa[i] = l0.wr[i] = 0;
-        vh_v_load(d, rs, st, 0, false, l0);
-        vh_v_pass<true>(d, l0, st, 0, 1, 0, true, lds, bad);
+        VLoad<CW> l0;
+        l0.clear_edges();
+        vh_v_load<CW>(d, rs, st, 0, false, l0);
+        vh_v_pass<CW, true>(d, l0, st, 0, 1, 0, true, lds, bad);
     }
     // Inside a stripe whose rows all exist the chunks of a segment are "inside" (every column and pair exists) up to the last
     // one or two: two loops in sequence, so that the edge forms stay out of the hot loop's code and registers.
     auto run = [&](auto edge_tag, int k0, int k1) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         for (int k = k0; k < k1; k++) {
-            const int c0 = xs + VH_CW * k;
+            const int c0 = xs + CW * k;
             const bool warm = sg > 0 && k == 0, first_true = sg == 0 && k == 0;
-            vh_h_to_lds(hin, lds);
+            vh_h_to_lds<CW>(hin, lds);
             __builtin_amdgcn_sched_barrier(0);  // (phase boundaries: the scheduler must not stretch the prefetch registers' lives)
-            vh_v_pass<EDGE>(d, vld, st, c0 + 1, 16, 1, !warm, lds, bad);
+            vh_v_pass<CW, EDGE>(d, vld, st, c0 + 1, CW, 1, !warm, lds, bad);
             lds_fence();
             __builtin_amdgcn_sched_barrier(0);
             if (k + 1 < nck) {  // (issued before the V pass -- a whole chunk ahead -- they cost 20 more registers and bought nothing)
-                vh_v_load(d, rs, st, c0 + VH_CW + 1, inside(c0 + VH_CW), vld);
-                vh_h_load(d, rs, st, c0 + VH_CW, inside(c0 + VH_CW), hin);
+                vh_v_load<CW>(d, rs, st, c0 + CW + 1, inside(c0 + CW), vld);
+                vh_h_load<CW>(d, rs, st, c0 + CW, inside(c0 + CW), hin);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int npairs = min(VH_CW, xe - c0);
-            const bool xcol = extra && npairs < VH_CW;
-            const int32_t a0 = first_true ? lds[threadIdx.x * VH_LD] : carry;
-            vh_h_pass<EDGE>(d, c0, warm, first_true, npairs, xcol, lds, a0, left, carry, bad);
+            const int npairs = min(CW, xe - c0);
+            const bool xcol = extra && npairs < CW;
+            const int32_t a0 = first_true ? lds[threadIdx.x * G::LD] : carry;
+            vh_h_pass<CW, EDGE>(d, c0, warm, first_true, npairs, xcol, lds, a0, left, carry, bad);
             lds_fence();
-            if (!warm) vh_store<EDGE>(d, rs, st, c0, 2 * npairs + (xcol ? 1 : 0), lds);
+            if (!warm) vh_store<CW, EDGE>(d, rs, st, c0, 2 * npairs + (xcol ? 1 : 0), lds);
             lds_fence();
             if (warm && grow < htot) d.side_h[(int64_t)sg * htot + grow] = left;  // the state this wave starts its own segment from
         }
     };
     int n_in = 0;
     if (stripe_inside) {
-        const int lim = min(d.w - 1, xe) - xs;  // inside(c0) <=> c0 + 16 <= min(w - 1, xe)
-        n_in = lim >= 0 ? min(nck, lim / VH_CW) : 0;
+        const int lim = min(d.w - 1, xe) - xs;  // inside(c0) <=> c0 + CW <= min(w - 1, xe)
+        n_in = lim >= 0 ? min(nck, lim / CW) : 0;
     }
     run(std::false_type{}, 0, n_in);
     run(std::true_type{}, n_in, nck);
     if (sg + 1 < d.nseg && grow < htot) d.tail_h[(int64_t)sg * htot + grow] = left;  // last output of this segment
     if (__builtin_expect(__any(bad), 0) && threadIdx.x == 0) atomicOr(bt.flag, 1);
+}
+
+__global__ __launch_bounds__(64, 3) void k_inv_vh(const VHBatch bt) {
+    __shared__ int32_t lds[VH_ROWS * VHG<16>::LD];
+    vh_body<16>(bt, lds);
+}
+// the wide form: 9 waves per CU by LDS, so the register budget of two waves per SIMD is free
+__global__ __launch_bounds__(64, 2) void k_inv_vh32(const VHBatch bt) {
+    __shared__ int32_t lds[VH_ROWS * VHG<32>::LD];
+    vh_body<32>(bt, lds);
 }
 
 __device__ __forceinline__ bool squeeze_check_one(const SqueezeCheck ck) {
@@ -406,11 +448,8 @@ __global__ __launch_bounds__(256) void k_squeeze_check(int n_chk, int32_t* flag,
 void launch_squeeze_vh(const VHBatch& bt, hipStream_t s) {
     if (bt.n <= 0 || bt.n_tiles <= 0) return;
     const int per = (bt.n_tiles + 7) / 8;
-#ifdef JXL_VH_ABL
-    const int abl = getenv("JXL_VH_ABL") ? atoi(getenv("JXL_VH_ABL")) : 0;
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_vh_abl), &abl, sizeof(int), 0, hipMemcpyHostToDevice, s);
-#endif
-    hipLaunchKernelGGL(k_inv_vh, dim3(8 * per), dim3(64), 0, s, bt);
+    if (bt.cw == 32) hipLaunchKernelGGL(k_inv_vh32, dim3(8 * per), dim3(64), 0, s, bt);
+    else hipLaunchKernelGGL(k_inv_vh, dim3(8 * per), dim3(64), 0, s, bt);
 }
 
 void launch_squeeze_check(const SqueezeCheck* chk, int n_chk, int32_t* flag, hipStream_t s) {

@@ -255,27 +255,30 @@ def _vh_inputs(rng, htot, wtot, nch=1, big=False):
 
 @pytest.mark.parametrize("htot,wtot", [(2, 2), (3, 3), (5, 34), (64, 32), (64, 66), (65, 65), (66, 130), (127, 97), (128, 256), (130, 257),
                                        (193, 67), (200, 1030), (321, 514), (1080, 1920)])
-@pytest.mark.parametrize("seg", [None, "16", "32", "64"])
-def test_fused_vh_pair(ctx, orc, htot, wtot, seg, monkeypatch):
+@pytest.mark.parametrize("seg,cw", [(None, None), ("16", "16"), ("32", "16"), ("64", "16"), ("32", "32"), ("64", "32"), (None, "32")])
+def test_fused_vh_pair(ctx, orc, htot, wtot, seg, cw, monkeypatch):
     """V + H of one level in one launch: every edge the tile walk has -- one stripe / several, ragged last stripe, odd height (the
     copied last row) and odd width (the copied last column), one segment / several with a ragged last one, the extra chunk that
     only holds the odd column -- against the oracle's two serial steps"""
-    if seg is None:
-        monkeypatch.delenv("JXL_VH_SEG", raising=False)
-    else:
-        monkeypatch.setenv("JXL_VH_SEG", seg)
+    for name, val in (("JXL_VH_SEG", seg), ("JXL_VH_CW", cw)):  # cw: chunk width of the kernel (16 / 32 H pairs), None = the library's choice
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, val)
     rng = np.random.default_rng(htot * 131 + wtot)
     chans, sp = _vh_inputs(rng, htot, wtot)
     ms = host.ModularStream(ctx, chans, sp)
     out = ms.applyTransforms()
     exp = orc.modular_apply(chans, sp)
     assert len(out) == len(exp) == 1 and out[0].shape == (htot, wtot)
-    assert_bits_equal(out[0], exp[0], "fused V+H %dx%d seg %s" % (htot, wtot, seg))
+    assert_bits_equal(out[0], exp[0], "fused V+H %dx%d seg %s cw %s" % (htot, wtot, seg, cw))
     assert ctx.lib.jxl_modular_last_launch_count(ctx.h) <= 2  # the pair + (at most) one check launch: the fused kernel ran
 
 
-def test_fused_vh_three_channels_and_rerun(ctx, orc, monkeypatch):
+@pytest.mark.parametrize("cw", ["16", "32"])
+def test_fused_vh_three_channels_and_rerun(ctx, orc, cw, monkeypatch):
     monkeypatch.setenv("JXL_VH_SEG", "32")
+    monkeypatch.setenv("JXL_VH_CW", cw)
     rng = np.random.default_rng(77)
     chans, sp = _vh_inputs(rng, 150, 201, nch=3)
     ms = host.ModularStream(ctx, chans, sp)
@@ -307,11 +310,13 @@ def test_fused_vh_int32_extremes_take_the_exact_path(ctx, orc):
     assert ctx.lib.jxl_modular_redo_count(ctx.h) >= before  # (white-noise extremes may or may not forget their start)
 
 
+@pytest.mark.parametrize("cw", ["16", "32"])
 @pytest.mark.parametrize("axis", ["h", "v"])
-def test_fused_vh_reports_adversarial_chains_and_redoes_in_order(ctx, orc, axis, monkeypatch):
+def test_fused_vh_reports_adversarial_chains_and_redoes_in_order(ctx, orc, axis, cw, monkeypatch):
     """chains that never forget their start (see _adversarial) across an H segment boundary / a V stripe or quarter boundary: the
     fused launch reports, the plan runs again with the one-step kernels in order, and the result is the serial walk's"""
     monkeypatch.setenv("JXL_VH_SEG", "32")
+    monkeypatch.setenv("JXL_VH_CW", cw)
     rng = np.random.default_rng(21)
     chans, sp = _vh_inputs(rng, 200, 300)
     if axis == "h":  # the V output is what the H step sees as averages: the forward V step of the adversarial rows
@@ -341,3 +346,18 @@ def test_fused_plan_equals_unfused_plan(ctx, orc, monkeypatch):
         assert_bits_equal(out[i], exp[i], "fused channel %d" % i)
         assert_bits_equal(out2[i], exp[i], "unfused channel %d" % i)
     assert fused_launches < ctx.lib.jxl_modular_last_launch_count(ctx.h)
+
+
+def test_fused_plan_repeats_bit_for_bit(ctx, orc):
+    """the same 1080p plan five times, every run against the oracle: the r5 store-data hazard (k_modular_vh.hip, vh_store: a VALU write
+    to the data registers of a 16-byte buffer store that has just issued) corrupted a few dozen samples per image, different ones from
+    run to run -- a parity test that runs a plan once can pass by luck"""
+    mod = synth.make_modular_frame(1920, 1080, channels=3, seed=3000)
+    exp = orc.modular_apply(mod["chans"], mod["sp"])
+    ms = host.ModularStream(ctx, mod["chans"], mod["sp"])
+    ms.begin()
+    for run in range(5):
+        ms.run()
+        got = ms.getDecodedBuffer()
+        for i in range(3):
+            assert_bits_equal(got[i], exp[i], "run %d channel %d" % (run, i))
