@@ -12,7 +12,7 @@
 //   H pass   lane = row: reads its row of A and of the H residuals R (staged through LDS by coalesced 16-byte loads), walks CW
 //            pairs serially from the chain state it carries in a register from chunk to chunk, and leaves every pair's two
 //            outputs in the two LDS slots the pair has just consumed.
-//   output   whole row pieces (8 CW bytes) leave LDS as 16-byte stores.
+//   output   whole row pieces (8 CW bytes) leave LDS as 8-byte stores (lane = (row, pair)).
 // CW = 32 (r5, the big steps): 128-byte input pieces and 256-byte output pieces -- the access shape of CW = 16 tops out at
 // ~3.8 TB/s of HBM traffic on this part, CW = 32 at ~4.7 (tools/ubench/vh_pattern.hip) -- and 1.5 x instead of 2 x redundant V
 // pairs (two halves of 16 + 8 instead of four quarters of 8 + 8), for 16.6 KB of LDS per wave instead of 8.4.
@@ -54,8 +54,6 @@ struct VHG {
     static constexpr int R0 = CW + 1;       // first H-residual slot of an LDS row
     static constexpr int HL = CW / 4;       // lanes per row of a 16-byte H-residual load
     static constexpr int HN = 64 / (64 / HL);  // such loads per chunk ( = HL )
-    static constexpr int SL = CW / 2;       // lanes per row of a 16-byte output store
-    static constexpr int SN = SL;           // such stores per chunk
 };
 
 // Orders this wave's LDS traffic: what other LANES wrote before it is visible to every read after it. One wave per workgroup, so no
@@ -288,36 +286,39 @@ __device__ __forceinline__ void vh_h_pass(const VHDesc& d, int c0, bool warm, bo
     if (!rg.ok(0)) bad = true;
 }
 
-// the chunk's 64 x 2 CW outputs: LDS rows -> global, 16 bytes per lane, whole row pieces
+// The chunk's 64 x 2 CW outputs: LDS rows -> global. Lane = (row, pair): the pair's two outputs are its slots A[i] and R[i] (one
+// ds_read2) and leave as ONE 8-byte store, a wave-instruction covering 64 / CW whole row pieces of 8 CW bytes.
+// Why not 16 bytes per lane: gfx950 store-data hazard. A 16-byte store still reads its data registers for two issue cycles after
+// it has issued, and a VALU write to one of them in that window reaches memory in some lanes (observed: the last four lanes of
+// every row of 16, one of the four dwords, differently from run to run -- the register allocator recycles v[2..3] of one store as
+// v[0..1] of the next). hipcc pads the hazard with s_nop itself, but not for buffer stores with a register in the soffset field
+// (its rule for older parts), and it counts an s_waitcnt as a wait state, which an already satisfied one is not: the first r5
+// builds got a few dozen samples per image wrong. Stores of at most 8 bytes have no such window; the 16-byte form measured no
+// faster (the stores of this access shape run at 6.8 TB/s either way, tools/ubench/vh_pattern.hip). tools/scan_store_hazard.py
+// (tests/test_isa_hazards.py) checks the ISA of every kernel of the library for the pattern.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 template <int CW, bool EDGE>
 __device__ __forceinline__ void vh_store(const VHDesc& d, const VHRsrc& rs, int st, int c0, int ncols, const int32_t* lds) {
     using G = VHG<CW>;
-    const int lane = threadIdx.x, pc = lane % G::SL;
+    constexpr int RPI = 64 / CW;  // rows per wave-instruction
+    const int lane = threadIdx.x, pi = lane % CW;
     const int ow = d.w + d.rw;
-    const int voff = ((lane / G::SL) * ow + 4 * pc) * 4;
-    int rstep = (64 / G::SL) * ow * 4;
+    const int voff = ((lane / CW) * ow + 2 * pi) * 4;
+    int rstep = RPI * ow * 4;
     asm volatile("" : "+s"(rstep));
     int so = (VH_ROWS * st * ow + 2 * c0) * 4;
-    const int32_t* src = lds + (lane / G::SL) * G::LD + 2 * pc;  // outputs 4 pc .. 4 pc + 3 = pairs 2 pc, 2 pc + 1: slots A[i] and R[i]
+    const int32_t* src = lds + (lane / CW) * G::LD + pi;
 #pragma unroll
-    for (int ps = 0; ps < G::SN; ps++, so += rstep) {
-        const int32_t* sp = src + (64 / G::SL) * ps * G::LD;
-        i32x4 v;
+    for (int ps = 0; ps < CW; ps++, so += rstep) {
+        const int32_t* sp = src + RPI * ps * G::LD;
+        i32x2 v;
         v[0] = sp[0];
         v[1] = sp[G::R0];
-        v[2] = sp[1];
-        v[3] = sp[G::R0 + 1];
         if (!EDGE) {
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs.o, voff, so, 0);
-            // gfx950: a 16-byte store still reads its data registers for a few cycles after it has issued, and a VALU write of
-            // one of them in that window reaches memory in some lanes (observed: the last four lanes of every row of 16, one of
-            // the four dwords, differently from run to run). hipcc pads that hazard only for stores WITHOUT a register in the
-            // soffset field (its rule for older parts); this one has one, and the register allocator recycles v[2..3] of one
-            // store as v[0..1] of the next. Four wait states by hand (two were enough in every run).
-            asm volatile("s_nop 3");
+            __builtin_amdgcn_raw_buffer_store_b64(v, rs.o, voff, so, 0);
         } else {  // rows below the plane are dropped by the range check (whole offset in the VGPR); columns beyond the chunk's last one must not be written
 #pragma unroll
-            for (int e = 0; e < 4; e++) __builtin_amdgcn_raw_buffer_store_b32(v[e], rs.o, 4 * pc + e < ncols ? voff + so + 4 * e : (int)kVhOob, 0, 0);
+            for (int e = 0; e < 2; e++) __builtin_amdgcn_raw_buffer_store_b32(v[e], rs.o, 2 * pi + e < ncols ? voff + so + 4 * e : (int)kVhOob, 0, 0);
         }
     }
 }
