@@ -106,23 +106,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 traffic["kernel_source_sha256"] = bench.kernel_source_sha()
 traffic["valu_wave_insts_per_launch"] = s["SQ_INSTS_VALU"]
-# every launch of ONE frame: per kernel, the sum of SQ_INSTS_VALU over its dispatches of the pass divided by the frames the pass
-# ran (= dispatches of the restoration kernel, one per frame)
-f_sq = find("sq", "*counter_collection.csv")
-tot, n_rest = collections.defaultdict(float), 0
-seen = set()
-for r in csv.DictReader(open(f_sq)):
-    if r["Counter_Name"] != "SQ_INSTS_VALU":
-        continue
-    k = short(r["Kernel_Name"])
-    tot[k] += float(r["Counter_Value"])
-    if k == rk and r["Dispatch_Id"] not in seen:
-        seen.add(r["Dispatch_Id"])
-        n_rest += 1
-if n_rest:
-    per_frame = {k: v / n_rest for k, v in tot.items() if "rocclr" not in k}
-    traffic["valu_wave_insts_all_launches_per_frame"] = sum(per_frame.values())
-    traffic["valu_wave_insts_by_kernel_per_frame"] = {k: round(v) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])}
+# every launch of ONE frame of the TIMED path: the IDCT-stage kernels and the restoration kernel, each launched once per frame (the
+# boundary legs of the same process -- widening, put_group, the RGB8 sink -- are not part of a step): mean SQ_INSTS_VALU per dispatch
+per_frame = {k: v["SQ_INSTS_VALU"] for k, v in sq.items() if "SQ_INSTS_VALU" in v and (k == rk or k.startswith(("k_idct", "k_llf", "k_large")))}
+traffic["valu_wave_insts_all_launches_per_frame"] = sum(per_frame.values())
+traffic["valu_wave_insts_by_kernel_per_frame"] = {k: round(v) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])}
 traffic["wait_any_share_of_wave_cycles"] = s.get("SQ_WAIT_ANY", 0) / max(s.get("SQ_WAVE_CYCLES", 1), 1)
 json.dump(traffic, open(os.path.join(out_dir, "%s_traffic.json" % tag), "w"), indent=1)
 lds_s = lds.get(rk, {})
