@@ -2869,7 +2869,8 @@ bool make_vh(jxl_ctx* c, const SqueezeBatch& v, const SqueezeBatch& h, VHBatch& 
     // chunk width: the wide form (128-byte input pieces, 256-byte output pieces, 1.5 x instead of 2 x redundant V pairs, 9 waves
     // per CU) where the step is bound by the memory system, i.e. where it got long segments; JXL_VH_CW forces one
     const int cw_env = getenv("JXL_VH_CW") ? atoi(getenv("JXL_VH_CW")) : 0;
-    int cw = seg >= 128 ? 32 : 16;
+    const int cw32_min = getenv("JXL_VH_CW32_MINSEG") ? atoi(getenv("JXL_VH_CW32_MINSEG")) : 128;
+    int cw = seg >= cw32_min ? 32 : 16;
     if (cw_env == 16 || cw_env == 32) cw = cw_env;
     if (cw == 32) seg = (seg + 31) & ~31;
     out.cw = cw;
