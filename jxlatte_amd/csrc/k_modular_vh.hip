@@ -38,6 +38,14 @@
 namespace jxl {
 namespace {
 
+#ifdef JXL_VH_ABL  // timing-only ablations (experiment builds, tools/r5_vh_abl.sh): 1 = no loads, 2 = no stores (zero-size descriptors:
+                   // the range check drops the accesses, the instruction stream stays), set per launch from the environment
+__device__ int g_vh_abl;
+#define VH_ABL(bit) (g_vh_abl & (bit))
+#else
+#define VH_ABL(bit) 0
+#endif
+
 constexpr int VH_ROWS = 64;  // output rows per tile
 constexpr int VH_WP = 8;     // warm-up pairs in front of every part of a V pass
 
@@ -361,10 +369,10 @@ __device__ __forceinline__ void vh_body(const VHBatch& bt, int32_t* lds) {
     const int nck = (xe + (extra ? 1 : 0) - xs + CW - 1) / CW;
     const bool stripe_inside = st >= 1 && 32 * st + 33 <= d.ah && 32 * st + 32 <= d.rh && VH_ROWS * st + VH_ROWS <= htot;
     VHRsrc rs;
-    rs.va = vh_rsrc(d.va, (int64_t)d.ah * d.w);
-    rs.vb = vh_rsrc(d.vb, (int64_t)d.rh * d.w);
-    rs.hb = vh_rsrc(d.hb, (int64_t)htot * d.rw);
-    rs.o = vh_rsrc(d.o, (int64_t)htot * (d.w + d.rw));
+    rs.va = vh_rsrc(d.va, VH_ABL(1) ? 0 : (int64_t)d.ah * d.w);
+    rs.vb = vh_rsrc(d.vb, VH_ABL(1) ? 0 : (int64_t)d.rh * d.w);
+    rs.hb = vh_rsrc(d.hb, VH_ABL(1) ? 0 : (int64_t)htot * d.rw);
+    rs.o = vh_rsrc(d.o, VH_ABL(2) ? 0 : (int64_t)htot * (d.w + d.rw));
     int32_t left = 0, carry = 0;
     bool bad = false;
     const int grow = VH_ROWS * st + threadIdx.x;
@@ -449,6 +457,10 @@ __global__ __launch_bounds__(256) void k_squeeze_check(int n_chk, int32_t* flag,
 void launch_squeeze_vh(const VHBatch& bt, hipStream_t s) {
     if (bt.n <= 0 || bt.n_tiles <= 0) return;
     const int per = (bt.n_tiles + 7) / 8;
+#ifdef JXL_VH_ABL
+    const int abl = getenv("JXL_VH_ABL") ? atoi(getenv("JXL_VH_ABL")) : 0;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_vh_abl), &abl, sizeof(int), 0, hipMemcpyHostToDevice, s);
+#endif
     if (bt.cw == 32) hipLaunchKernelGGL(k_inv_vh32, dim3(8 * per), dim3(64), 0, s, bt);
     else hipLaunchKernelGGL(k_inv_vh, dim3(8 * per), dim3(64), 0, s, bt);
 }
