@@ -253,7 +253,14 @@ void jxl_host_free(void* p);
  * (the device counterpart of walking HFMetadata.blockList, HFCoefficients.java:76-85), the chroma-from-luma
  * cache-order masks (HFCoefficients.java:159-181), upload of the side tables, LF dequantisation jobs. Synchronous.
  * Idempotent until the frame's inputs change; jxl_vardct_run calls it implicitly. bench.py times it as
- * `host_prepare_ms`. */
+ * `host_prepare_ms`.
+ * Deliberate refusal (JXL_ERR_UNSUPPORTED): a varblock with a 128- or 256-sample edge in a CHROMA-SUBSAMPLED frame. The
+ * reference transforms every channel's copy of such a block at the channel's own geometry (PassGroup.java:203-233,
+ * TransformType.java:10-36), where the copies of neighbouring blocks overlap in the subsampled planes and the later one
+ * overwrites the earlier: its output depends on its visiting order, no encoder emits such frames (libjxl's only subsampled
+ * frames are JPEG recompressions, DCT8 throughout), and a device that transforms blocks concurrently has no such order to
+ * reproduce. Frames without subsampling take these blocks through the three-launch path of k_idct.hip (dequantise, column
+ * pass, row pass through a scratch plane). */
 jxl_status jxl_vardct_prepare(jxl_ctx* ctx);
 /* Launch every enabled stage on the ctx stream; inputs are resident after put_group.
  * Asynchronous: returns after enqueue. Re-runnable (inputs are not consumed). */
