@@ -399,6 +399,25 @@ __global__ __launch_bounds__(256) void k_squeeze_chain(const SqueezeBatch* __res
                         na[q] = an[q];
                     }
                     if (j0 + RV < rdim) fetch(j0 + RV, rn, an);
+                    // r5: whole chunks whose samples pass the range guard walk with the sign-normalised short form (modular_tend.h:
+                    // 13 instead of ~25 dependent instructions per pair); the guard is per lane (nothing here is shared between
+                    // lanes), a chunk that fails it and the ragged last chunk take the reference's form
+                    SqueezeRange rg;
+                    rg.init(a);
+#pragma unroll
+                    for (int q = 0; q < RV; q++) rg.add(na[q], rr[q]);
+                    if (j0 + RV < adim && j0 + RV <= rdim && rg.ok(left)) {
+#pragma unroll
+                        for (int q = 0; q < RV; q++) {
+                            const int j = j0 + q;
+                            int32_t first, second;
+                            left = squeeze_pair_n(left, tend_n_pre(a, na[q], rr[q]), first, second);
+                            d.o[ob + (int64_t)(2 * j) * os] = first;
+                            d.o[ob + (int64_t)(2 * j + 1) * os] = second;
+                            a = na[q];
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int q = 0; q < RV; q++) {
                         const int j = j0 + q;
