@@ -2860,7 +2860,7 @@ bool make_vh(jxl_ctx* c, const SqueezeBatch& v, const SqueezeBatch& h, VHBatch& 
     int seg = 256;
     auto tiles_with = [&](int sg) {
         int64_t t = 0;
-        for (int i = 0; i < v.n; i++) t += (int64_t)((v.d[i].adim + v.d[i].rdim + 63) / 64) * ((h.d[i].rdim + sg - 1) / sg);
+        for (int i = 0; i < v.n; i++) t += (int64_t)((v.d[i].adim + v.d[i].rdim + 63) / 64) * std::max(1, (h.d[i].rdim - 1 + sg - 1) / sg);
         return t;
     };
     while (seg > 32 && tiles_with(seg) < want) seg >>= 1;
@@ -2886,7 +2886,7 @@ bool make_vh(jxl_ctx* c, const SqueezeBatch& v, const SqueezeBatch& h, VHBatch& 
         d.rh = v.d[i].rdim;
         d.rw = h.d[i].rdim;
         d.seg = seg;
-        d.nseg = (d.rw + seg - 1) / seg;
+        d.nseg = std::max(1, (d.rw - 1 + seg - 1) / seg);  // segment s covers the pairs [s == 0 ? 0 : 1 + s seg, 1 + (s + 1) seg)
         d.nstripe = (d.ah + d.rh + 63) / 64;
         d.tile0 = tile0;
         tile0 += d.nseg * d.nstripe;
@@ -3007,17 +3007,39 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
     c->mod_ops.clear();
     c->mod_ops_fused.clear();
     c->mod_out.clear();
-    auto alloc = [&](size_t n_elems) -> int32_t* {
+    // Every plane starts kVhPad samples into its allocation (kVhPadH for a plane that is the residual of a horizontal step): the
+    // fused squeeze kernel (k_modular_vh.hip) tiles the H pairs in chunks that start at pairs 1, 1 + CW, 1 + 2 CW, ..., and with
+    // these leads the pieces it loads (V inputs from column c0 + 1, H residuals from pair c0) and the pieces it stores (outputs
+    // from column 2 c0) all begin on 128-byte lines wherever a row's pitch is a multiple of 128 bytes -- the big levels.
+    auto alloc_pad = [&](size_t n_elems, int pad) -> int32_t* {
         c->mod_bufs.emplace_back();
-        if (!c->mod_bufs.back().ensure(4 * std::max<size_t>(1, n_elems))) return nullptr;
-        return c->mod_bufs.back().as<int32_t>();
+        if (!c->mod_bufs.back().ensure(4 * (std::max<size_t>(1, n_elems) + 64))) return nullptr;
+        return c->mod_bufs.back().as<int32_t>() + pad;
     };
+    auto alloc = [&](size_t n_elems) -> int32_t* { return alloc_pad(n_elems, kVhPad); };
+    // which input channels are residuals of horizontal steps: a dry walk over the steps, as the loop below
+    std::vector<uint8_t> is_hres((size_t)std::max(n_chans, 0), 0);
+    {
+        std::vector<int> idx((size_t)std::max(n_chans, 0));
+        for (int i = 0; i < n_chans; i++) idx[i] = i;
+        for (int j = n_sp - 1; j >= 0; j--) {
+            const int begin = sp[j].begin_c, end = begin + sp[j].num_c - 1, n = (int)idx.size();
+            const int offset = sp[j].in_place ? end + 1 : n + begin - end - 1;
+            if (begin < 0 || end < begin || end >= n || offset < 0 || offset + (end - begin) >= n) break;  // (reported below)
+            for (int k = begin; k <= end; k++) {
+                const int r = offset + k - begin;
+                if (sp[j].horizontal && idx[r] >= 0) is_hres[idx[r]] = 1;
+                idx[k] = -1;  // the step's output
+            }
+            idx.erase(idx.begin() + offset, idx.begin() + offset + (end - begin + 1));
+        }
+    }
     std::vector<ModChan> ch;
     for (int i = 0; i < n_chans; i++) {
         if (chans[i].width < 0 || chans[i].height < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "negative channel size");
         const size_t n = (size_t)chans[i].width * chans[i].height;
         if (n && !chans[i].data) return fail(c, JXL_ERR_INVALID_ARGUMENT, "channel %d has no data", i);
-        int32_t* d = alloc(n);
+        int32_t* d = alloc_pad(n, is_hres[i] ? kVhPadH : kVhPad);
         if (!d) return fail(c, JXL_ERR_OOM, "device allocation failed (modular channel)");
         if (n) HIP_TRY(c, hipMemcpy(d, chans[i].data, 4 * n, hipMemcpyHostToDevice));
         ch.push_back(ModChan{chans[i].width, chans[i].height, d, true});

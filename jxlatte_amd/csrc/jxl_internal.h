@@ -279,6 +279,7 @@ constexpr int kSqueezeMaxChecks = 16;
 // 16 H pairs (k_modular_vh.hip). Guessed states, all verified like the segmented walk's (SqueezeCheck): the H chain at a segment
 // start (side_h / tail_h, [nseg][rows]), the V chain at a stripe start (side_v / tail_v, [nstripe][columns]), and the V chain at
 // the three quarter boundaries inside a stripe (compared inside the wave, reported in VHBatch::flag).
+constexpr int kVhPad = 30, kVhPadH = 31;  // samples in front of a plane / of a horizontal step's residual plane (host.hip, jxl_modular_begin)
 struct VHDesc {
     const int32_t* va;  // V averages  [ah][w]
     const int32_t* vb;  // V residuals [rh][w]
@@ -286,7 +287,7 @@ struct VHDesc {
     int32_t* o;         // output      [ah + rh][w + rw]
     int w, ah, rh, rw;  // rh >= 1, rw >= 1; ah - rh and w - rw are 0 or 1
     int seg;            // H pairs per segment (a multiple of VHBatch::cw)
-    int nseg, nstripe;  // ceil(rw / seg), ceil((ah + rh) / 64)
+    int nseg, nstripe;  // max(1, ceil((rw - 1) / seg)), ceil((ah + rh) / 64)
     int tile0;          // index of this channel's first tile in the launch (tiles: [stripe][segment])
     int32_t *side_h, *tail_h;  // [nseg][ah + rh]
     int32_t *side_v, *tail_v;  // [ceil(rh / 32)][w]

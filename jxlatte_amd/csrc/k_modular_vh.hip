@@ -16,9 +16,9 @@
 // CW = 32 (r5, the big steps): 128-byte input pieces and 256-byte output pieces -- the access shape of CW = 16 tops out at
 // ~3.8 TB/s of HBM traffic on this part, CW = 32 at ~4.7 (tools/ubench/vh_pattern.hip) -- and 1.5 x instead of 2 x redundant V
 // pairs (two halves of 16 + 8 instead of four quarters of 8 + 8), for 16.6 KB of LDS per wave instead of 8.4.
-// The V pass of a chunk produces columns c0+1 .. c0+16 (the H pair at column c needs column c + 1 as its `next average`); column
-// c0 itself is the last column of the previous chunk and is handed on in a register. Output stores and H-residual loads stay
-// line-aligned; only the V input pieces are shifted by one sample.
+// The V pass of a chunk produces columns c0+1 .. c0+CW (the H pair at column c needs column c + 1 as its `next average`); column
+// c0 itself is the last column of the previous chunk and is handed on in a register. The chunks start at pairs 1, 1 + CW, ... and
+// every plane has a leading pad (kVhPad), so that V-input pieces, H-residual pieces and output pieces all start on a line.
 //
 // Guessed states and their verification (results are bit-identical to the serial walk whenever nothing is reported):
 //   * H chain at a segment start: the segment walks one chunk (15 pairs) early and stores nothing for it; side_h / tail_h;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void vh_v_load(const VHDesc& d, const VHRsrc& rs, int
             }
         }
     } else {
-        int vo = ((32 * st + G::KP * q) * w + min(cfirst + j, w - 1)) * 4;
+        int vo = ((32 * st + G::KP * q) * w + min(max(cfirst + j, 0), w - 1)) * 4;
         const int vo0 = vo - VH_WP * w4;
 #pragma unroll
         for (int i = 0; i < G::KP; i++, vo += w4) {
@@ -164,8 +164,8 @@ __device__ __forceinline__ void vh_v_pass(const VHDesc& d, const VLoad<CW>& ld, 
     const int lane = threadIdx.x, q = lane / CW, j = lane % CW;
     const int w = d.w;
     const int ybase = 32 * st + KP * q - VH_WP;
-    const int col = min(cfirst + j, w - 1);
-    const bool colok = !EDGE || (j < nc && cfirst + j < w);
+    const int col = min(max(cfirst + j, 0), w - 1);
+    const bool colok = !EDGE || (j < nc && cfirst + j >= 0 && cfirst + j < w);
     const bool wr = !EDGE || j < nc;
     int32_t* p = lds + (2 * KP * q) * G::LD + slot0 + j;
     auto warm_a = [&](int i) { const int32_t t = __shfl_up(ld.a[KP - VH_WP + i], CW); return q == 0 ? ld.wa[i] : t; };
@@ -260,12 +260,11 @@ __device__ __forceinline__ void vh_h_to_lds(const HIn<CW>& in, int32_t* lds) {
 // The row's samples are read from LDS as the walk reaches them; pair i leaves its two outputs in the two slots it has just
 // consumed (its average A[i] -- slot 0 is spare -- and its residual R[i]): nothing of the row has to sit in registers.
 template <int CW, bool EDGE>
-__device__ __forceinline__ void vh_h_pass(const VHDesc& d, int c0, bool warm, bool first_true, int npairs, bool extra, int32_t* lds,
+__device__ __forceinline__ void vh_h_pass(const VHDesc& d, int c0, bool warm, int npairs, bool extra, int32_t* lds,
                                           int32_t a0, int32_t& left, int32_t& carry, bool& bad) {
     using G = VHG<CW>;
     int32_t* row = lds + threadIdx.x * G::LD;
     int32_t a = warm ? row[1] : a0;
-    if (first_true) left = a;  // the row's first pair uses its own average (ModularChannel.java:370)
     SqueezeRange rg;
     rg.init(a);
     if (!rg.ok(left)) bad = true;
@@ -326,7 +325,8 @@ __device__ __forceinline__ void vh_store(const VHDesc& d, const VHRsrc& rs, int 
             __builtin_amdgcn_raw_buffer_store_b64(v, rs.o, voff, so, 0);
         } else {  // rows below the plane are dropped by the range check (whole offset in the VGPR); columns beyond the chunk's last one must not be written
 #pragma unroll
-            for (int e = 0; e < 2; e++) __builtin_amdgcn_raw_buffer_store_b32(v[e], rs.o, 2 * pi + e < ncols ? voff + so + 4 * e : (int)kVhOob, 0, 0);
+            for (int e = 0; e < 2; e++)
+                __builtin_amdgcn_raw_buffer_store_b32(v[e], rs.o, 2 * pi + e < ncols ? voff + so + 4 * e : (int)kVhOob, 0, 0);
         }
     }
 }
@@ -363,10 +363,15 @@ __device__ __forceinline__ void vh_body(const VHBatch& bt, int32_t* lds) {
     const int local = t - d.tile0;
     const int st = local / d.nseg, sg = local - st * d.nseg;
     const int htot = d.ah + d.rh;
-    const int xb = sg * d.seg, xe = min(d.rw, xb + d.seg);
-    const int xs = sg > 0 ? xb - CW : 0;
+    // The chunks of a row start at pairs 1, 1 + CW, 1 + 2 CW, ... (pair 0 is done on its own in front of them): with the planes'
+    // leading pads (kVhPad / kVhPadH, host.hip) the V-input pieces (from column c0 + 1), the H-residual pieces (from pair c0) and the
+    // output pieces (from column 2 c0) then all start on 128-byte lines. r5, first form: chunks from pair 0 -- the V pieces started
+    // one sample late, every line of V input was requested by two consecutive chunks ~10 us apart and fetched twice
+    // (TCC_EA0_RDREQ x 128 B = 1.77 x the input bytes).
+    const int xb = sg == 0 ? 0 : 1 + sg * d.seg, xe = min(d.rw, 1 + (sg + 1) * d.seg);
+    const int xs = sg > 0 ? xb - CW : 1;                // first chunk: the warm-up chunk, or the one at pair 1
     const bool extra = sg == d.nseg - 1 && d.w > d.rw;  // the odd last output column belongs to the last segment
-    const int nck = (xe + (extra ? 1 : 0) - xs + CW - 1) / CW;
+    const int nck = max(0, (xe + (extra ? 1 : 0) - xs + CW - 1) / CW);
     const bool stripe_inside = st >= 1 && 32 * st + 33 <= d.ah && 32 * st + 32 <= d.rh && VH_ROWS * st + VH_ROWS <= htot;
     VHRsrc rs;
     rs.va = vh_rsrc(d.va, VH_ABL(1) ? 0 : (int64_t)d.ah * d.w);
@@ -384,11 +389,31 @@ __device__ __forceinline__ void vh_body(const VHBatch& bt, int32_t* lds) {
     vld.clear_edges();
     vh_v_load<CW>(d, rs, st, xs + 1, inside(xs), vld);
     vh_h_load<CW>(d, rs, st, xs, inside(xs), hin);
-    if (sg == 0) {  // column 0 has no chunk to its left that would have produced it
+    if (sg == 0) {
+        // pair 0 of every row, in front of the chunk grid: V-output columns 0 and 1 (slots 0 and 1), then the pair itself -- its
+        // left neighbour is its own average (ModularChannel.java:370) -- and column 1 is what the chunk at pair 1 starts from
         VLoad<CW> l0;
         l0.clear_edges();
         vh_v_load<CW>(d, rs, st, 0, false, l0);
-        vh_v_pass<CW, true>(d, l0, st, 0, 1, 0, true, lds, bad);
+        vh_v_pass<CW, true>(d, l0, st, 0, 2, 0, true, lds, bad);
+        lds_fence();
+        if (grow < htot) {
+            const int32_t* row = lds + threadIdx.x * G::LD;
+            const int32_t a = row[0], nx = 1 < d.w ? row[1] : a;
+            const int32_t r = d.hb[(int64_t)grow * d.rw];
+            SqueezeRange rg;
+            rg.init(a);
+            rg.add(nx, r);
+            if (!rg.ok(a)) bad = true;
+            int32_t f, s2;
+            squeeze_pair_n(a, tend_n_pre(a, nx, r), f, s2);
+            int32_t* o = d.o + (int64_t)grow * (d.w + d.rw);
+            o[0] = f;
+            o[1] = s2;
+            left = s2;
+            carry = row[1];
+        }
+        lds_fence();
     }
     // Inside a stripe whose rows all exist the chunks of a segment are "inside" (every column and pair exists) up to the last
     // one or two: two loops in sequence, so that the edge forms stay out of the hot loop's code and registers.
@@ -396,7 +421,7 @@ __device__ __forceinline__ void vh_body(const VHBatch& bt, int32_t* lds) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         for (int k = k0; k < k1; k++) {
             const int c0 = xs + CW * k;
-            const bool warm = sg > 0 && k == 0, first_true = sg == 0 && k == 0;
+            const bool warm = sg > 0 && k == 0;
             vh_h_to_lds<CW>(hin, lds);
             __builtin_amdgcn_sched_barrier(0);  // (phase boundaries: the scheduler must not stretch the prefetch registers' lives)
             vh_v_pass<CW, EDGE>(d, vld, st, c0 + 1, CW, 1, !warm, lds, bad);
@@ -409,8 +434,7 @@ __device__ __forceinline__ void vh_body(const VHBatch& bt, int32_t* lds) {
             __builtin_amdgcn_sched_barrier(0);
             const int npairs = min(CW, xe - c0);
             const bool xcol = extra && npairs < CW;
-            const int32_t a0 = first_true ? lds[threadIdx.x * G::LD] : carry;
-            vh_h_pass<CW, EDGE>(d, c0, warm, first_true, npairs, xcol, lds, a0, left, carry, bad);
+            vh_h_pass<CW, EDGE>(d, c0, warm, npairs, xcol, lds, carry, left, carry, bad);
             lds_fence();
             if (!warm) vh_store<CW, EDGE>(d, rs, st, c0, 2 * npairs + (xcol ? 1 : 0), lds);
             lds_fence();
