@@ -339,3 +339,29 @@ def test_groups_never_put_read_as_zero_also_on_a_reused_context(ctx, orc):
     f.commitCoeffsI16(np.ones(9, np.uint8))
     assert_bits_equal(f.decodeFrame(), full, "mapped planes")
     assert_bits_equal(frame([2]), expected([2]), "one group put behind a frame committed from mapped planes")
+
+
+@pytest.mark.gpu
+def test_frame_geometry_queries(ctx):
+    """jxl_vardct_geometry / jxl_vardct_group_size (r5): the numbers the JNI shim sizes its buffer checks from -- plane sizes and
+    shifts per channel (paddedSize >> jpegUpsampling, HFCoefficients.java:64-69), the output sample size, and the rectangle of a
+    group (Frame.getGroupLocation / getGroupSize, J/frame/Frame.java:767-786) incl. the ragged last column and row of groups"""
+    import ctypes as C
+    base = synth.make_vardct_frame(528, 272, seed=5, mix="dct8", xyb=0)
+    fr = synth.make_subsampled(base, (1, 0, 1), (1, 0, 0))
+    f = host.Frame.from_synth(ctx, fr, stages=abi.STAGE_IDCT)
+    info = (C.c_int32 * 13)()
+    ctx.call("jxl_vardct_geometry", info)
+    W, H = f.width, f.height
+    assert list(info)[:6] == [W >> 1, W, W, H >> 1, H, H >> 1]
+    assert list(info)[6:12] == [1, 1, 0, 0, 0, 1] and info[12] == 4
+    gw, gh = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    grs, gcs = (W + 255) // 256, (H + 255) // 256
+    ctx.call("jxl_vardct_group_size", 0, gw, gh)
+    assert list(gw) == [128, 256, 256] and list(gh) == [128, 256, 128]
+    ctx.call("jxl_vardct_group_size", grs * gcs - 1, gw, gh)
+    lw, lh = W - 256 * (grs - 1), H - 256 * (gcs - 1)
+    assert list(gw) == [lw >> 1, lw, lw] and list(gh) == [lh >> 1, lh, lh >> 1]
+    from jxlatte_amd import _lib
+    with pytest.raises(_lib.IllegalArgumentException):
+        ctx.call("jxl_vardct_group_size", grs * gcs, gw, gh)
