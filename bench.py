@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--stages", type=int, default=31, help="stage mask (diagnostics): 1 IDCT, 2 Gab, 4 EPF, 8 XYB, 16 out")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the collective legs even with one rank")
     ap.add_argument("--verify", action="store_true", help="check frame 0 against the oracle before timing")
+    ap.add_argument("--streaming-child", default="", help="internal: run the streaming boundary leg alone (device,contexts,frames_per_context,job.pkl) and print its JSON")
     return ap.parse_args(argv)
 
 
@@ -151,9 +152,25 @@ def jvm_probe(sample_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def streaming_child(spec):
+    """the streaming boundary leg in a process of its own (bench.py's parent passes device, contexts, frames per context and the
+    expected pixels): no torch, no other contexts or streams of the timed legs, and the runtime setting a multi-decoder host
+    runs with (GPU_MAX_HW_QUEUES, set by the parent before this process initialises HIP)"""
+    import pickle
+    dev, n_ctx, fpc, path = spec.split(",", 3)
+    from jxlatte_amd import _lib, abi, host
+    with open(path, "rb") as f:
+        job = pickle.load(f)  # the parent's frame, its parameter block and the pixels it got for it
+    p = abi.VarDCTParams.from_buffer_copy(job["params"])
+    r = streaming_leg(_lib, host, job["frame"], p, int(dev), job["npx"], job["ref"], int(n_ctx), int(fpc), in_child=True)
+    print(json.dumps(r))
+
+
 def main():
     global _REAL_STDOUT
     args = parse()
+    if args.streaming_child:
+        return streaming_child(args.streaming_child)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     # RCCL prints a version banner on stdout when the first communicator is created; keep stdout clean for the
@@ -723,8 +740,102 @@ def synth_num_groups(d):
     return synth.num_groups(d)
 
 
-def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "8")), frames_per_ctx=8):
+class _StreamBenchArgs(C.Structure):  # tools/native/stream_bench.cpp: jxl_stream_bench_args
+    _fields_ = [("lib_path", C.c_char_p), ("device", C.c_int32), ("n_ctx", C.c_int32), ("frames_per_ctx", C.c_int32),
+                ("params", C.c_void_p), ("weights", C.c_void_p), ("n_weights", C.c_size_t), ("woffs", C.c_void_p),
+                ("lfgroups", C.c_void_p), ("n_lfgroups", C.c_int32), ("coeff", C.c_void_p * 3), ("rows", C.c_int32 * 3),
+                ("cols", C.c_int32 * 3), ("group_written", C.c_void_p), ("n_groups", C.c_int32), ("outs", C.c_void_p),
+                ("out_stride", C.c_int64), ("wall_s", C.c_double), ("phase_s", C.c_double * 8), ("err", C.c_char * 256)]
+
+
+STREAM_PHASES = ("begin", "lfgroups", "prepare", "map", "stores", "commit", "wait_prev+run", "read_begin")
+
+
+def streaming_leg_native(_lib, host, d, p, device, npx, ref_out, n_ctx, frames_per_ctx):
+    """the streaming leg from native host threads (tools/native/stream_bench.cpp): the call sequence of streaming_leg() below,
+    one std::thread per context -- what a JVM host's decoder threads do; Python threads serialise on the interpreter lock
+    between the calls. None when the helper is not built."""
+    from jxlatte_amd import abi
+    so = os.path.join(ROOT, "jxlatte_amd", "libjxl_stream_bench.so")
+    if not os.path.exists(so) or os.environ.get("JXL_BENCH_STREAM_PY"):
+        return None
+    drv = C.CDLL(so)
+    drv.jxl_stream_bench.restype = C.c_int
+    drv.jxl_stream_bench.argtypes = [C.POINTER(_StreamBenchArgs)]
+    lib = _lib.load()
+    coeff16 = [np.ascontiguousarray(a, np.int16) for a in d["coeff"]]
+    weights = np.ascontiguousarray(d["weights"], np.float32)
+    woffs = np.ascontiguousarray(d["woffs"], np.int32)
+    descs = [abi.make_lfgroup_desc(g) for g in d["lfgroups"]]
+    dptr = (C.c_void_p * len(descs))(*[C.addressof(x) for x in descs])
+    written = np.ones(synth_num_groups(d), np.uint8)
+    pouts = [host.PinnedArray(lib, ref_out.shape, ref_out.dtype) for _ in range(n_ctx)]
+    try:
+        optr = (C.c_void_p * n_ctx)(*[x.array.ctypes.data for x in pouts])
+        a = _StreamBenchArgs()
+        a.lib_path = _lib.SO_PATH.encode()
+        a.device, a.n_ctx, a.frames_per_ctx = device, n_ctx, frames_per_ctx
+        a.params = C.addressof(p)
+        a.weights, a.n_weights, a.woffs = weights.ctypes.data, weights.size, woffs.ctypes.data
+        a.lfgroups, a.n_lfgroups = C.addressof(dptr), len(descs)
+        for ch in range(3):
+            a.coeff[ch] = coeff16[ch].ctypes.data
+            a.rows[ch], a.cols[ch] = coeff16[ch].shape
+        a.group_written, a.n_groups = written.ctypes.data, written.size
+        a.outs, a.out_stride = C.addressof(optr), p.width
+        if drv.jxl_stream_bench(C.byref(a)) != 0:
+            return {"error": a.err.decode("utf-8", "replace")}
+        same = [bool(np.array_equal(x.array, ref_out)) for x in pouts]
+    finally:
+        for x in pouts:
+            x.free()
+    n = n_ctx * frames_per_ctx
+    return {"contexts": n_ctx, "frames": n, "host_threads": "native (tools/native/stream_bench.cpp)", "wall_ms": round(a.wall_s * 1e3, 2),
+            "ms_per_frame": round(a.wall_s * 1e3 / n, 3), "streaming_end_to_end_Mpx_s": round(npx * n / a.wall_s / 1e6, 1),
+            "identical_output": all(same),
+            "host_ms_per_frame_and_thread": dict(zip(STREAM_PHASES, [round(float(v) / n * 1e3, 2) for v in a.phase_s])),
+            "note": "%d contexts, one native host thread each (a JVM host's decoder threads; no interpreter lock between the calls): "
+                    "begin_frame + LF groups + prepare + map (no zero-fill: every group is written) + coefficient stores + commit + run + "
+                    "read_output_begin per frame, read_output_wait one frame later (RGB8); all frames through the whole boundary; "
+                    "PCIe-inclusive, never `value`" % n_ctx}
+
+
+STREAM_HW_QUEUES = "16"  # GPU_MAX_HW_QUEUES of the streaming leg's process (the runtime's default is 4)
+
+
+def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "8")),
+                  frames_per_ctx=int(os.environ.get("JXL_BENCH_STREAM_FRAMES", "24")), in_child=False):
     import threading
+    if not in_child and not os.environ.get("JXL_BENCH_STREAM_INPROC"):
+        # a process of its own: eight contexts and their streams share the runtime's hardware queues -- 4 by default, and a table
+        # copy or an IDCT launch of one context then waits behind the other contexts' bus transfers (begin_frame 1.5-3.8 ms per
+        # call; tools/r5_stream_sections.sh). GPU_MAX_HW_QUEUES is read when the runtime initialises, so the leg that stands for
+        # a multi-decoder host gets its own process with the setting INTEGRATION.md recommends; the timed step keeps the default
+        # (it is 1-3 % slower with 16 queues).
+        import pickle
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            ref_path = os.path.join(td, "job.pkl")
+            with open(ref_path, "wb") as f:
+                pickle.dump({"frame": d, "params": bytes(p), "npx": npx, "ref": ref_out}, f, protocol=4)
+            env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("JXL_BENCH_STREAM_HW_QUEUES", STREAM_HW_QUEUES))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--streaming-child", "%d,%d,%d,%s" % (device, n_ctx, frames_per_ctx, ref_path)],
+                               env=env, capture_output=True, text=True, timeout=600)
+        try:
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            return {"error": "streaming child failed: " + (r.stderr or r.stdout)[-300:]}
+        res["process"] = "own process, GPU_MAX_HW_QUEUES=%s" % env["GPU_MAX_HW_QUEUES"]
+        return res
+    nat = streaming_leg_native(_lib, host, d, p, device, npx, ref_out, n_ctx, frames_per_ctx)
+    if nat is not None:
+        if os.environ.get("JXL_BENCH_STREAM_BOTH"):  # diagnostics: the Python-thread form beside it
+            os.environ["JXL_BENCH_STREAM_PY"] = "1"
+            try:
+                nat["python_threads"] = streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx, frames_per_ctx)
+            finally:
+                del os.environ["JXL_BENCH_STREAM_PY"]
+        return nat
     lib = _lib.load()
     coeff16 = [np.ascontiguousarray(a, np.int16) for a in d["coeff"]]
     all_groups = np.ones(synth_num_groups(d), np.uint8)
@@ -807,8 +918,8 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
     n = n_ctx * frames_per_ctx
     return {"contexts": n_ctx, "frames": n, "wall_ms": round(wall * 1e3, 2), "ms_per_frame": round(wall * 1e3 / n, 3),
             "streaming_end_to_end_Mpx_s": round(npx * n / wall / 1e6, 1), "identical_output": all(same),
-            "host_ms_per_frame_and_thread": dict(zip(("begin", "lfgroups", "prepare", "map", "stores", "commit", "wait_prev+run", "read_begin"),
-                                                     [round(float(v), 2) for v in sum(phases) / n * 1e3])),
+            "host_threads": "python",
+            "host_ms_per_frame_and_thread": dict(zip(STREAM_PHASES, [round(float(v), 2) for v in sum(phases) / n * 1e3])),
             "note": "%d contexts, one host thread each: begin_frame + LF groups + prepare + map (no zero-fill: every group is written) + "
                     "coefficient stores + commit (3 DMA transfers of int16 planes) + run + read_output_begin per frame, read_output_wait "
                     "one frame later (RGB8); all frames through the whole boundary; PCIe-inclusive, never `value`" % n_ctx}

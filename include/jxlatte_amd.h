@@ -282,7 +282,11 @@ jxl_status jxl_vardct_read_output(jxl_ctx* ctx, void* const out[3], int64_t out_
  * until they have landed. In between the host may drive the NEXT frame of this context (begin_frame ... commit ... run: its
  * device work queues behind the copies), which is how one context overlaps the host's share of frame n+1 with the device's share
  * of frame n -- what the reference's one-frame-at-a-time loop (JXLCodestreamDecoder.decode, :506-720) leaves on the table. The
- * destination must stay valid until _wait and should be page-locked (jxl_host_alloc) for the copy to be a queued DMA. */
+ * destination must stay valid until _wait and should be page-locked (jxl_host_alloc): a page-locked, 16-byte aligned destination
+ * with dense rows is written by a kernel through its device alias (r5: no runtime copy call -- with several contexts streaming
+ * frames each hipMemcpyAsync held its caller for 1.6-2.5 ms), anything else goes through the runtime's copy. A host that runs
+ * several decoder contexts should start with GPU_MAX_HW_QUEUES=16 in its environment (the runtime's default of 4 hardware
+ * queues makes one context's launches wait behind the others' bus transfers). */
 jxl_status jxl_vardct_read_output_begin(jxl_ctx* ctx, void* const out[3], int64_t out_stride);
 jxl_status jxl_vardct_read_output_wait(jxl_ctx* ctx);
 /* ---- the frame's colour planes kept on the device between the stages that follow decodeFrame --------------------------

@@ -71,6 +71,22 @@ def build(force=False, verbose=False, tag=None, defines=()):
     return so
 
 
+def build_stream_bench(force=False):
+    """the native host-thread driver of bench.py's streaming boundary leg (tools/native/stream_bench.cpp; g++, no device code):
+    a measurement harness beside the library, reaching it through dlopen"""
+    src = os.path.join(HERE, "..", "tools", "native", "stream_bench.cpp")
+    so = os.path.join(HERE, "libjxl_stream_bench.so")
+    inc = os.path.join(HERE, "..", "include")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(inc, "jxlatte_amd.h"))):
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-I", inc, src, "-o", so, "-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("stream_bench build failed:\n%s" % r.stderr[-4000:])
+    return so
+
+
 if __name__ == "__main__":
     tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), None)
     print(build(force="--force" in sys.argv, verbose=True, tag=tag, defines=[a[2:] for a in sys.argv if a.startswith("-D")]))
+    if not tag:
+        print(build_stream_bench(force="--force" in sys.argv))

@@ -172,6 +172,7 @@ struct jxl_ctx {
     DevBuf batch_wg3_args;
     void* h_map16 = nullptr;   // page-locked frame-sized int16 planes handed to the caller (jxl_vardct_map_coeffs_i16)
     bool map16_nofill = false;       // mapped without zero-fill: commit must be told which groups were written
+    bool is_feeder = false;          // counted in g_feeders (bus_grid): this context has mapped coefficient planes
     hipEvent_t map16_ev = nullptr;   // "the commit's transfers have read h_map16": what the next map waits for (not the whole stream)
     bool map16_inflight = false;
     hipEvent_t out_ev = nullptr;     // jxl_vardct_read_output_begin's copies
@@ -322,14 +323,70 @@ __global__ void k_widen2d(int32_t* plane, int W, int y0, int x0, const int16_t* 
 // read requests and needs no SDMA transfer, no device staging buffer and no host API call per plane besides this launch.
 // gw % 8 == 0, gh % 8 == 0. A workgroup takes 32 cells of a cell row: 32 consecutive lanes read 512 consecutive bytes of one
 // sample row (the PCIe side keeps its long runs), the 8 rows of the workgroup complete every cell it touches.
-__global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ plane, const int16_t* __restrict__ src, int gw, int gh) {
-    const int r = threadIdx.x >> 5, bx = blockIdx.x * 32 + (threadIdx.x & 31), by = blockIdx.y;
-    if (bx * 8 >= gw) return;
+// r5: a bounded grid walks the tiles (JXL_WIDEN_GRID workgroups, default 128): the transfer runs at the bus's rate with a few
+// hundred requests in flight, and a launch that parks a wave on every slot of the chip while it waits for the bus starves the
+// other contexts' IDCT / restoration kernels of their slots (streaming: those ran 3-5 x longer beside a widening launch).
+__global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ plane, const int16_t* __restrict__ src, int gw, int gh, int gx, int tiles) {
+    // a tile = one cell row x 64 cells: a wave reads 1 KB of consecutive samples of a row (two rows per wave, both loads in flight)
+    const int wv = threadIdx.x >> 6, lx = threadIdx.x & 63;
     typedef int v4i_ __attribute__((ext_vector_type(4)));
-    const v4i_ pk = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(src + (int64_t)(by * 8 + r) * gw + bx * 8));
-    int32_t* d = plane + (((int64_t)by * (gw >> 3) + bx) << 6) + r * 8;
-    *reinterpret_cast<v4i_*>(d) = v4i_{(pk.x << 16) >> 16, pk.x >> 16, (pk.y << 16) >> 16, pk.y >> 16};
-    *reinterpret_cast<v4i_*>(d + 4) = v4i_{(pk.z << 16) >> 16, pk.z >> 16, (pk.w << 16) >> 16, pk.w >> 16};
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int by = t / gx, bx = (t - by * gx) * 64 + lx;
+        if (bx * 8 >= gw) continue;
+        const int16_t* sp = src + (int64_t)(by * 8 + wv * 2) * gw + bx * 8;
+        const v4i_ p0 = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sp));
+        const v4i_ p1 = __builtin_nontemporal_load(reinterpret_cast<const v4i_*>(sp + gw));
+        // 8-byte stores (kept apart by compiler barriers, or the back end merges them again): the kernel waits on the bus, not on its stores, and a 16-byte store followed at once by the next unpack
+        // into its data registers is the gfx950 store-data hazard of DESIGN 4.3 (tools/scan_store_hazard.py flags the 16-byte form)
+        typedef int v2i_ __attribute__((ext_vector_type(2)));
+        v2i_* d = reinterpret_cast<v2i_*>(plane + (((int64_t)by * (gw >> 3) + bx) << 6) + wv * 16);
+        d[0] = v2i_{(p0.x << 16) >> 16, p0.x >> 16}; asm volatile("" ::: "memory");
+        d[1] = v2i_{(p0.y << 16) >> 16, p0.y >> 16}; asm volatile("" ::: "memory");
+        d[2] = v2i_{(p0.z << 16) >> 16, p0.z >> 16}; asm volatile("" ::: "memory");
+        d[3] = v2i_{(p0.w << 16) >> 16, p0.w >> 16}; asm volatile("" ::: "memory");
+        d[4] = v2i_{(p1.x << 16) >> 16, p1.x >> 16}; asm volatile("" ::: "memory");
+        d[5] = v2i_{(p1.y << 16) >> 16, p1.y >> 16}; asm volatile("" ::: "memory");
+        d[6] = v2i_{(p1.z << 16) >> 16, p1.z >> 16}; asm volatile("" ::: "memory");
+        d[7] = v2i_{(p1.w << 16) >> 16, p1.w >> 16};
+    }
+}
+
+// r5: transfers between page-locked host memory and the device as KERNELS that move 16 bytes per lane through the host buffer's
+// device alias, on a bounded grid. With several contexts streaming frames from several host threads, every hipMemcpyAsync of a frame
+// (the side tables in, the pixels out) held its calling thread for 1.6-2.6 ms -- the runtime's copy path waits on the host for the
+// stream's earlier work -- while a launch returns in microseconds (tools/r5_stream_sections.sh, profiles/r5_stream_*.txt).
+typedef int v4i_cp __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const v4i_cp* __restrict__ src, v4i_cp* __restrict__ dst, size_t n16, size_t tail_bytes) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += step) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    if (blockIdx.x == 0 && threadIdx.x < tail_bytes)
+        reinterpret_cast<uint8_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint8_t*>(src + n16)[threadIdx.x];
+}
+
+// queue dst[0, bytes) = src[0, bytes) on the context's stream as a launch of k_copy16; the host side (dst if dst_is_host, else src)
+// must be page-locked and both sides 16-byte aligned. false: not possible (pageable memory) -- the caller takes the runtime's copy
+bool copy_zero(jxl_ctx* c, void* dst, const void* src, size_t bytes, bool dst_is_host, int grid) {
+    if (!bytes || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return false;
+    void* alias = nullptr;
+    if (hipHostGetDevicePointer(&alias, const_cast<void*>(dst_is_host ? dst : src), 0) != hipSuccess || !alias) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const size_t n16 = bytes >> 4;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((size_t)grid, (n16 + 255) / 256 + 1)), dim3(256), 0, c->stream,
+                       static_cast<const v4i_cp*>(dst_is_host ? src : alias), static_cast<v4i_cp*>(dst_is_host ? alias : dst), n16, bytes & 15);
+    return true;
+}
+
+// How many workgroups a bus transfer of this context gets. One bounded launch per direction moves 45-57 GB/s each way; many
+// waves of BOTH kinds in flight -- what several contexts streaming frames produce -- drop the link to 55 GB/s for the two
+// directions together (tools/ubench/pcie_duplex: 128 + 128 workgroups 90 GB/s, 1024 + 1024 55 GB/s). So the grid shrinks
+// with the number of live contexts that feed frames through the mapped planes (g_feeders): alone 128 workgroups, eight
+// contexts 32 (in) / 16 (out) each -- streaming 4K frames: 1.37 ms per frame against 1.46 with 128 everywhere.
+std::atomic<int> g_feeders[64];
+int bus_grid(const jxl_ctx* c, bool out) {
+    const int n = std::max(1, c->device >= 0 && c->device < 64 ? g_feeders[c->device].load(std::memory_order_relaxed) : 1);
+    return n <= 2 ? 128 : std::max(out ? 16 : 32, (out ? 128 : 256) / n);
 }
 
 bool is_small(int t) { return JXL_TT[t].ph == 8 && JXL_TT[t].pw == 8; }
@@ -378,8 +435,27 @@ void tab_bind_fixed(jxl_ctx* c, size_t nc, size_t nt) {
     c->h_kb = {reinterpret_cast<float*>(c->h_tab + c->off_kb), nt};
     for (int i = 0; i < 3; i++) c->h_lf[i] = {reinterpret_cast<float*>(c->h_tab + c->off_lf[i]), nc};
 }
+// diagnostics (JXL_PREPARE_TIMING): host time of a call's sections, to stderr
+struct SectTimer {
+    const char* who;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit SectTimer(const char* w) : who(w) {
+        static const bool e = getenv("JXL_PREPARE_TIMING") != nullptr;
+        on = e;
+        if (on) t = std::chrono::steady_clock::now();
+    }
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[%s] %-28s %.3f ms\n", who, what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 // begin_frame: lay the fixed sections out, make room (plus a first guess for the block records), fill the defaults
 bool tab_begin_frame(jxl_ctx* c, size_t nc, size_t nt) {
+    SectTimer tm("begin");
     size_t o = 0;
     c->off_hfm = o; o = tab_up(o + 4 * nc);
     c->off_sharp = o; o = tab_up(o + 4 * nc);
@@ -388,13 +464,16 @@ bool tab_begin_frame(jxl_ctx* c, size_t nc, size_t nt) {
     for (int i = 0; i < 3; i++) { c->off_lf[i] = o; o = tab_up(o + 4 * nc); }
     c->tab_fixed = o;
     tab_wait(c);  // the previous frame's transfer may still be reading the buffer
+    tm.mark("tab_wait");
     if (!tab_reserve(c, o + sizeof(DevBlock) * nc / 2 + 65536, 0)) return false;
     tab_bind_fixed(c, nc, nt);
+    tm.mark("reserve");
     std::fill(c->h_hf_mul.begin(), c->h_hf_mul.end(), 1);
     memset(c->h_sharp.data(), 0, 4 * nc);
     memset(c->h_kx.data(), 0, 4 * nt);
     memset(c->h_kb.data(), 0, 4 * nt);
     for (int i = 0; i < 3; i++) memset(c->h_lf[i].data(), 0, 4 * nc);
+    tm.mark("defaults");
     return true;
 }
 
@@ -712,7 +791,9 @@ jxl_status finalize_tables(jxl_ctx* c) {
     }
     mark("staging");
     if (!c->tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->tab_ev, hipEventDisableTiming));
-    HIP_TRY(c, hipMemcpyAsync(c->tab.p, c->h_tab, total, hipMemcpyHostToDevice, c->stream));
+    static const bool tab_zero = !(getenv("JXL_TABLE_ZEROCOPY") && atoi(getenv("JXL_TABLE_ZEROCOPY")) == 0);
+    if (!(tab_zero && c->h_tab_pinned && copy_zero(c, c->tab.p, c->h_tab, total, false, 64)))
+        HIP_TRY(c, hipMemcpyAsync(c->tab.p, c->h_tab, total, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(c->tab_ev, c->stream));
     c->tab_inflight = true;
     {
@@ -1155,6 +1236,7 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
 
 void jxl_ctx_destroy(jxl_ctx* c) {
     if (!c) return;
+    if (c->is_feeder) g_feeders[c->device].fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->lut, &c->hf_mul, &c->sharp, &c->xfy, &c->bfy, &c->weights, &c->weights_t, &c->inv_sigma, &c->blocks, &c->items,
@@ -1253,6 +1335,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     c->bw = c->W / 8; c->bh = c->H / 8;
     c->tw = ceil_div(c->bw, 8); c->th = ceil_div(c->bh, 8);
     const size_t npx = (size_t)c->W * c->H, nc = (size_t)c->bw * c->bh, nt = (size_t)c->tw * c->th;
+    SectTimer tm("begin2");
     bool ok = true;
     for (int i = 0; i < 3; i++) {
         ok = ok && c->coeff[i].ensure(4 * npx) && c->planeA[i].ensure(4 * npx) && c->planeB[i].ensure(4 * npx) &&
@@ -1260,8 +1343,11 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
         if (out_interleaved(p->out_format)) ok = ok && (i > 0 || c->outbuf[0].ensure(3 * (size_t)out_elem_size(p->out_format) * npx));
         else if (p->out_format != JXL_OUT_F32 || p->transfer != JXL_TRANSFER_NONE) ok = ok && c->outbuf[i].ensure(4 * npx);
     }
-    ok = ok && c->inv_sigma.ensure(4 * nc) && tab_begin_frame(c, nc, nt);
+    ok = ok && c->inv_sigma.ensure(4 * nc);
+    tm.mark("ensure");
+    ok = ok && tab_begin_frame(c, nc, nt);
     if (!ok) return fail(c, JXL_ERR_OOM, "device allocation failed for a %dx%d frame", c->W, c->H);
+    tm.mark("tab_begin_frame");
     c->coeff_zero_pending = true;  // new int[sY][sX] (HFCoefficients.java:68): zeroed when a group is put / the frame runs
     c->out_zero_pending = true;    // frame buffer starts zeroed (ImageBuffer ctor): zeroed at run time if a cell has no varblock
     c->h_sel.assign(nc, 255);
@@ -1276,6 +1362,7 @@ jxl_status jxl_vardct_begin_frame(jxl_ctx* c, const jxl_vardct_params* p) {
     c->map16_valid = false;
     c->ev_runs = 0;
     c->result[0] = c->result[1] = c->result[2] = nullptr;
+    tm.mark("host vectors");
     return JXL_OK;
 }
 
@@ -1579,6 +1666,10 @@ jxl_status jxl_vardct_map_coeffs_i16_ex(jxl_ctx* c, int16_t* planes[3], int32_t 
     // previous frame's kernels and its output copy no longer hold the host back)
     if (c->map16_inflight && c->map16_ev) HIP_TRY(c, hipEventSynchronize(c->map16_ev));
     c->map16_inflight = false;
+    if (!c->is_feeder && c->device >= 0 && c->device < 64) {
+        c->is_feeder = true;
+        g_feeders[c->device].fetch_add(1, std::memory_order_relaxed);
+    }
     if (c->h_map16_bytes < off[3]) {
         if (c->h_map16) (void)hipHostFree(c->h_map16);
         c->h_map16 = nullptr;
@@ -1648,6 +1739,12 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
     if (written && n_groups != grs * gcs) return fail(c, JXL_ERR_INVALID_ARGUMENT, "commit: %d group flags for a frame of %d groups", n_groups, grs * gcs);
     if (!written && c->map16_nofill) return fail(c, JXL_ERR_STATE, "planes mapped with JXL_MAP_NO_FILL: commit with the list of written groups");
     size_t off = 0;
+    static const bool zero_copy = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
+    void* hdev = nullptr;
+    bool all8 = true;
+    for (int ch = 0; ch < 3; ch++) all8 = all8 && (((c->W >> c->sx[ch]) & 7) == 0);
+    const bool zc = zero_copy && all8 && hipHostGetDevicePointer(&hdev, c->h_map16, 0) == hipSuccess && hdev;
+    if (!zc) (void)hipGetLastError();
     for (int ch = 0; ch < 3; ch++) {
         const int Wc = c->W >> c->sx[ch], Hc = c->H >> c->sy[ch];
         const size_t bytes = (size_t)Wc * Hc * sizeof(int16_t);
@@ -1668,15 +1765,15 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
         // runtime call per plane instead of two. With a dozen contexts committing from a dozen threads the hipMemcpyAsync calls
         // had become the slowest part of a frame (commit 2-3 ms per frame and thread against 0.06; tools/r4_zerocopy_ab.sh).
         // JXL_COMMIT_ZEROCOPY=0: the staged form
-        static const bool zero_copy = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
-        void* hdev = nullptr;
-        if (zero_copy && (Wc & 7) == 0 && hipHostGetDevicePointer(&hdev, c->h_map16, 0) == hipSuccess && hdev) {
-            hipLaunchKernelGGL(k_widen2d_host8, dim3(ceil_div(Wc / 8, 32), Hc / 8), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(),
-                               reinterpret_cast<const int16_t*>(static_cast<char*>(hdev) + off), Wc, Hc);
+        if (zc) {
+            static const int wgrid_env = getenv("JXL_WIDEN_GRID") ? std::max(1, atoi(getenv("JXL_WIDEN_GRID"))) : 0;
+            const int wgrid = wgrid_env ? wgrid_env : bus_grid(c, false);
+            const int gx = ceil_div(Wc / 8, 64), tiles = gx * (Hc / 8);
+            hipLaunchKernelGGL(k_widen2d_host8, dim3(std::min(wgrid, tiles)), dim3(256), 0, c->stream, c->coeff[ch].as<int32_t>(),
+                               reinterpret_cast<const int16_t*>(static_cast<char*>(hdev) + off), Wc, Hc, gx, tiles);
             off += (bytes + 255) & ~(size_t)255;
             continue;
         }
-        (void)hipGetLastError();
         if (!c->stage16.ensure(c->h_map16_bytes)) return fail(c, JXL_ERR_OOM, "device allocation failed (int16 staging)");
         int16_t* stg = reinterpret_cast<int16_t*>(static_cast<char*>(c->stage16.p) + off);
         HIP_TRY(c, hipMemcpyAsync(stg, static_cast<char*>(c->h_map16) + off, bytes, hipMemcpyHostToDevice, c->stream));
@@ -2240,6 +2337,14 @@ jxl_status jxl_vardct_last_stage_ms(jxl_ctx* c, int32_t which, float* ms) {
 int32_t jxl_vardct_out_elem_size(const jxl_ctx* c) { return c ? c->result_elem : 0; }
 int32_t jxl_vardct_last_launch_count(const jxl_ctx* c) { return c ? c->last_launches : 0; }
 
+// r5: a result buffer in page-locked memory is written by a kernel over PCIe (copy_zero, above) instead of through hipMemcpyAsync.
+// JXL_OUTPUT_ZEROCOPY=0: the runtime's copy.
+static bool copy_out_zero(jxl_ctx* c, void* dst, const void* src, size_t bytes) {
+    static const bool on = !(getenv("JXL_OUTPUT_ZEROCOPY") && atoi(getenv("JXL_OUTPUT_ZEROCOPY")) == 0);
+    static const int grid_env = getenv("JXL_OUTPUT_GRID") ? std::max(1, atoi(getenv("JXL_OUTPUT_GRID"))) : 0;
+    return on && copy_zero(c, dst, src, bytes, true, grid_env ? grid_env : bus_grid(c, true));
+}
+
 // the copies of the last run's result planes to the host, queued on the context's stream
 static jxl_status enqueue_output(jxl_ctx* c, void* const out[3], int64_t out_stride) {
     if (!c->result[0]) return fail(c, JXL_ERR_STATE, "nothing has been run");
@@ -2250,15 +2355,19 @@ static jxl_status enqueue_output(jxl_ctx* c, void* const out[3], int64_t out_str
     const bool dense = out_stride == c->W;
     if (c->result_interleaved) {  // one buffer, rows of 3*W samples; out_stride counts pixels
         if (!out[0]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output buffer");
-        if (dense) HIP_TRY(c, hipMemcpyAsync(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost, c->stream));
-        else HIP_TRY(c, hipMemcpy2DAsync(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
+        if (dense) {
+            if (!copy_out_zero(c, out[0], c->result[0], (size_t)c->W * 3 * es * c->H))
+                HIP_TRY(c, hipMemcpyAsync(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost, c->stream));
+        } else HIP_TRY(c, hipMemcpy2DAsync(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
                                          hipMemcpyDeviceToHost, c->stream));
         return JXL_OK;
     }
     for (int i = 0; i < 3; i++) {
         if (!out[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane %d", i);
-        if (dense) HIP_TRY(c, hipMemcpyAsync(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost, c->stream));
-        else HIP_TRY(c, hipMemcpy2DAsync(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H,
+        if (dense) {
+            if (!copy_out_zero(c, out[i], c->result[i], (size_t)c->W * es * c->H))
+                HIP_TRY(c, hipMemcpyAsync(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost, c->stream));
+        } else HIP_TRY(c, hipMemcpy2DAsync(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H,
                                          hipMemcpyDeviceToHost, c->stream));
     }
     return JXL_OK;
