@@ -94,6 +94,9 @@ struct jxl_stream_bench_args {
     char err[256];
 };
 
+// the binding's layout check (bench.py's ctypes mirror)
+size_t jxl_stream_bench_args_size(void) { return sizeof(jxl_stream_bench_args); }
+
 int jxl_stream_bench(jxl_stream_bench_args* a) {
     Api api;
     a->err[0] = 0;
