@@ -803,7 +803,7 @@ def streaming_leg_native(_lib, host, d, p, device, npx, ref_out, n_ctx, frames_p
 STREAM_HW_QUEUES = "16"  # GPU_MAX_HW_QUEUES of the streaming leg's process (the runtime's default is 4)
 
 
-def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "8")),
+def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.get("JXL_BENCH_STREAM_CTX", "10")),
                   frames_per_ctx=int(os.environ.get("JXL_BENCH_STREAM_FRAMES", "24")), in_child=False):
     import threading
     if not in_child and not os.environ.get("JXL_BENCH_STREAM_INPROC"):
