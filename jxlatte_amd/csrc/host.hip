@@ -2026,9 +2026,32 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         void* dst[3];
         for (int i = 0; i < 3; i++) dst[i] = do_out ? c->outbuf[i].p : (void*)oth[i];
         const float* src[3] = {cur[0], cur[1], cur[2]};
+        // r5: three EPF iterations as TWO launches -- Gaborish + the 13-tap iteration on a 64x32 tile into the other plane set, then
+        // the two-iteration kernel (no Gaborish) from there. Fused in one launch, the 13-tap iteration runs on the whole 64x32
+        // window of a 58x26 output tile (1.36 x its pixels) and its 118 registers hold ALL stages of the kernel to 2 workgroups
+        // per CU; split, it runs once per pixel, and the second launch is the 63-register kernel at 4 workgroups per CU. The
+        // planes cross HBM once more (200 MB per 4K frame, under the launches' arithmetic). JXL_EPF3_SPLIT=0: one launch.
+        static const bool epf3_split = !(getenv("JXL_EPF3_SPLIT") && atoi(getenv("JXL_EPF3_SPLIT")) == 0);
+        const bool split = epf3_split && rp.epf_iters == 3 && c->W >= 8 && c->H >= 8;
+        if (collect && split) {
+            if (collected) *collected = false;  // (jxl_vardct_run_batch: this frame launches its own pair)
+            return JXL_OK;
+        }
         if (collect) {
             fused = fill_restore_fused_args(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, *collect);
             if (collected) *collected = fused;
+        } else if (split) {
+            RestoreParams ra = rp, rb = rp;
+            ra.epf_iters = 4;  // restore_fused_body.h: the 13-tap iteration alone
+            ra.xyb = 0; ra.transfer = JXL_TRANSFER_NONE; ra.max_value = 0; ra.out_elem = 4; ra.interleaved = 0;
+            rb.gab = 0; rb.epf_iters = 2;
+            void* mid[3] = {oth[0], oth[1], oth[2]};
+            if (!do_out)
+                for (int i = 0; i < 3; i++) dst[i] = cur[i];  // the input planes are dead once the first launch has read them
+            const float* mids[3] = {oth[0], oth[1], oth[2]};
+            fused = launch_restore_fused(src, mid, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), ra, s) &&
+                    launch_restore_fused(mids, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rb, s);
+            if (fused) launches++;
         } else {
             fused = launch_restore_fused(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, s);
         }

@@ -52,11 +52,18 @@ __device__ __forceinline__ int mirror_c(int c, int size) {
 template <bool GAB, int ITERS>
 struct Geo {
     static constexpr int RG = GAB ? 1 : 0;
-    static constexpr int R0 = ITERS == 3 ? 3 : 0;
-    static constexpr int R1 = ITERS >= 1 ? 2 : 0;
-    static constexpr int R2 = ITERS >= 2 ? 1 : 0;
+    // ITERS = 4: the 13-tap iteration ALONE (the first half of a three-iteration frame run as two launches, k_restore_fused.hip)
+    static constexpr int R0 = (ITERS == 3 || ITERS == 4) ? 3 : 0;
+    static constexpr int R1 = (ITERS >= 1 && ITERS <= 3) ? 2 : 0;
+    static constexpr int R2 = (ITERS == 2 || ITERS == 3) ? 1 : 0;
     static constexpr int SHR = ITERS == 3 ? (R1 + R2) : ITERS == 2 ? R2 : 0;  // window -> output tile
-    static constexpr int OW = 64 - 2 * SHR, OH = 32 - 2 * SHR;               // output tile
+#ifndef JXL_EPF0_WH
+#define JXL_EPF0_WH 64
+#endif
+    // the 13-tap iteration alone has no later stage to shrink for, and its 118 registers hold it to 2 workgroups per CU whatever the
+    // tile costs in LDS: a 64 x 64 window (66 KB) loads and Gab-filters 1.27 x / 1.20 x its pixels instead of 1.41 x / 1.30 x
+    static constexpr int WH = ITERS == 4 ? JXL_EPF0_WH : 32;                  // window height
+    static constexpr int OW = 64 - 2 * SHR, OH = WH - 2 * SHR;               // output tile
     static constexpr int RE = R0 + R1 + R2;
     static constexpr int RT = RE + RG;                                        // input halo
     static constexpr int IW = OW + 2 * RT, IH = OH + 2 * RT;                  // input tile
@@ -629,6 +636,11 @@ __device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
         }
         return;
     }
+    if (ITERS == 4) {  // iteration 0 on the whole 64x32 window, straight to the sink
+        m += 3;
+        epf_stage<0, G, true, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
+        return;
+    }
     if (ITERS == 3) {
         m += 3;
         epf_stage<0, G, false, PH>(cur, m, tc, sig, scy0, scx0, a.p.epf[0], sink);
@@ -647,7 +659,7 @@ __device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
     }
 }
 
-#define JXL_RESTORE_BOUNDS(ITERS, PH) __launch_bounds__(512 / PH, ITERS == 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_WAVES) : PH == 1 ? 8 : 4)
+#define JXL_RESTORE_BOUNDS(ITERS, PH) __launch_bounds__(512 / PH, ITERS >= 3 ? (PH == 1 ? 4 : JXL_EPF3_PH2_WAVES) : PH == 1 ? 8 : 4)
 // occupancy floor: 8 waves per SIMD (64 VGPRs); the 3-iteration variant holds 48 tap distances per patch and spilled 130
 // VGPRs at that bound, so it is allowed 128 registers (4 waves per SIMD; its 43 KB tile allows 3 workgroups per CU anyway)
 template <bool GAB, int ITERS, int SK, int PH>
@@ -705,12 +717,16 @@ void launch_fused_sk(const FusedArgs& a, hipStream_t s) {
         if (it == 0) launch_tph<true, 0, SK, 1>(a, s);
         else if (it == 1) launch_tph<true, 1, SK, 1>(a, s);
         else if (it == 2) launch_tph<true, 2, SK, 1>(a, s);
-        else launch_tph<true, 3, SK, 1>(a, s);
+        else if (it == 4) {
+            if constexpr (SK == SK_PLAIN) launch_tph<true, 4, SK_PLAIN, 1>(a, s);  // (float planes only: the first half of a split run)
+        } else launch_tph<true, 3, SK, 1>(a, s);
     } else {
         if (it == 0) launch_tph<false, 0, SK, 1>(a, s);
         else if (it == 1) launch_tph<false, 1, SK, 1>(a, s);
         else if (it == 2) launch_tph<false, 2, SK, 1>(a, s);
-        else launch_tph<false, 3, SK, 1>(a, s);
+        else if (it == 4) {
+            if constexpr (SK == SK_PLAIN) launch_tph<false, 4, SK_PLAIN, 1>(a, s);
+        } else launch_tph<false, 3, SK, 1>(a, s);
     }
 }
 template <int SK>
