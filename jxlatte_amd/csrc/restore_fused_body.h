@@ -10,6 +10,8 @@
 // 64x32 window = 512 threads x (4 wide x 1 tall) register patches (PH = 2: 256 threads x 4x2 patches, measured slower). Later
 // iterations shrink the window by their radius (iteration 1: 2 px of input halo, iteration 2: 1, iteration 0: 3), Gaborish
 // adds 1. E.g. the default (Gab + iterations 1,2): input tile 70x38 -> Gab 68x36 -> EPF1 64x32 -> EPF2 62x30 output tile.
+// r5: a frame with three iterations runs as TWO launches (host.hip run_frame): ITERS = 4 -- Gaborish + the 13-tap iteration alone on a
+// 64x64 tile, float planes out -- and ITERS = 2 without Gaborish from there; ITERS = 3 (all in one launch) stays for JXL_EPF3_SPLIT=0.
 // ONE LDS image of 3 planes (~34 KB) that every stage updates IN PLACE: a thread computes the patch it owns into registers, the
 // workgroup meets at a barrier (all reads of the old values done), then the patches are written back over the input
 // (4 workgroups per CU = 8 waves per SIMD at 63 VGPRs).
