@@ -108,6 +108,9 @@ __shared__ unsigned long long g_stamp_lds[24];
 // would be waited for at the next barrier and the software pipeline would collapse (measured: the first version of this
 // kernel was slower than the unpipelined one). Nothing a barrier of this kernel separates goes through global memory.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef JXL_ABL_WG3_NOBAR  // timing experiment (wrong results): the waves of a workgroup never meet
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -205,8 +208,13 @@ __device__ __forceinline__ void load_blk(Blk<KC>& b, cfloatp lut /* row n0-1, th
 // steps n0 .. n0+3 (n0 even): even steps add to the mirrored half, odd steps subtract
 template <int KC>
 __device__ __forceinline__ void mac_blk(Acc3<KC>& acc, const Blk<KC>& b) {
+#ifdef JXL_ABL_WG3_NOMAC  // timing experiment (wrong results): one step of four is multiplied and added
+#pragma unroll
+    for (int u = 0; u < 1; u++) {
+#else
 #pragma unroll
     for (int u = 0; u < 4; u++) {
+#endif
         const v2f s[3] = {v2f{b.s[u][0], b.s[u][0]}, v2f{b.s[u][1], b.s[u][1]}, v2f{b.s[u][2], b.s[u][2]}};
 #pragma unroll
         for (int j = 0; j < KC / 4; j++)
@@ -443,7 +451,11 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             // cell-tiled int32 planes (coeff_off): cell (py >> 3, px >> 3), 64 samples each
             const int64_t off = (((int64_t)(py >> 3) * cells_w + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));
 #pragma unroll
+#ifdef JXL_ABL_WG3_NOLOAD  // timing experiment (wrong results): no coefficient is read
+            for (int c = 0; c < 3; c++) raw.q[j][c] = v4i{(int)(off & 3), c, tid & 1, 0};
+#else
             for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const __attribute__((address_space(1))) v4i*>(cp[c] + off);
+#endif
             // chromaFromLuma factors of the tile this group lies in (4 consecutive x from a multiple of 4 never cross a
             // 64-px boundary), honouring the reference's per-group cache order (DevBlock::cfl_zero)
             const int ty = py >> 6, tx = px >> 6;
