@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--stages", type=int, default=31, help="stage mask (diagnostics): 1 IDCT, 2 Gab, 4 EPF, 8 XYB, 16 out")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) and run the collective legs even with one rank")
     ap.add_argument("--verify", action="store_true", help="check frame 0 against the oracle before timing")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` object (the other workloads north_star names, each run as a child process after the headline)")
     ap.add_argument("--streaming-child", default="", help="internal: run the streaming boundary leg alone (device,contexts,frames_per_context,job.pkl) and print its JSON")
     return ap.parse_args(argv)
 
@@ -113,6 +114,60 @@ def spawn_ranks(args):
                     procs[q].terminate()
         time.sleep(0.05)
     return rc
+
+
+ALSO_RUNS = (
+    # key, extra arguments, what it is
+    ("modular8k", ["--workload", "modular8k", "--frames-per-gpu", "1"], "8K Modular (7680x4320x3, default squeeze plan), one image alone"),
+    ("modular8k_x4", ["--workload", "modular8k", "--frames-per-gpu", "4", "--no-cpu-baseline"], "the same, four images in flight"),
+    ("modular1080p", ["--workload", "modular1080p", "--frames-per-gpu", "1"], "config C2: one 1080p Modular image alone"),
+    ("vardct8k_pq", ["--workload", "vardct8k_pq", "--no-cpu-baseline"], "config C4: 8K VarDCT, XYB -> linear -> PQ u16 (2 frames per step)"),
+    ("vardct4k_epf1", ["--epf-iters", "1", "--no-cpu-baseline"], "the headline workload with 1 EPF iteration (SURVEY 8(d))"),
+    ("vardct4k_epf3", ["--epf-iters", "3", "--no-cpu-baseline"], "the headline workload with 3 EPF iterations (SURVEY 8(d))"),
+)
+
+
+def also_runs(args):
+    """The other workloads north_star names -- 8K Modular (1 and 4 in flight), config C2 (1080p Modular), config C4 (8K PQ), the 1- and
+    3-iteration EPF runs -- measured by THIS command so that the driver's line carries them: each is this script
+    as a child process (fresh contexts, same timing rules: warm-up, then K steps between synchronisations), started only after the
+    headline's timed region and its other legs are over, so nothing shares the device with `value`. Never folded into `value`."""
+    out = {}
+    t0 = time.time()
+    for key, extra, what in ALSO_RUNS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--no-gather", "--no-end-to-end", "--no-also"] + extra
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        a = time.time()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not js:
+                out[key] = {"what": what, "error": "exit %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+                continue
+            d = json.loads(js[-1])
+        except Exception as ex:  # a failed side run must not cost the headline its line
+            out[key] = {"what": what, "error": repr(ex)[:300]}
+            continue
+        rf = d.get("roofline") or {}
+        e = {"what": what, "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "dtype": d.get("dtype"),
+             "workload": (d.get("config") or {}).get("workload"),
+             "frac": rf.get("path_frac") if rf.get("path_frac") is not None else rf.get("frac"),
+             "frac_of": "whole path, algorithmic bytes / elapsed / 8 TB/s" if rf.get("path_frac") is not None else "algorithmic bytes (24 B/px) / elapsed / 8 TB/s",
+             "kernel_frac": rf.get("frac") if rf.get("path_frac") is not None else None,
+             "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"), "run_s": round(time.time() - a, 1)}
+        if (d.get("config") or {}).get("single_frame_ms") is not None:
+            e["single_frame_ms"] = d["config"]["single_frame_ms"]
+        if d.get("cpu_baseline"):
+            e["cpu_baseline"] = d["cpu_baseline"]
+        out[key] = e
+    out["note"] = ("each entry: `python bench.py <arguments of ALSO_RUNS>` as a child process after the headline's legs, %d steps after %d warm-up "
+                   "steps; `traffic` = HBM bytes per launch / plan from profiles/*traffic.json while the kernel sources hash to what was "
+                   "profiled, else null; never part of `value`; %.0f s in all" % (args.steps, args.warmup, time.time() - t0))
+    return out
+
 
 
 def cpu_model():
@@ -401,7 +456,7 @@ def main():
     # the bench; the figures are carried over only when workload and variant match, else null.
     traffic, valu_insts, traffic_src, valu_all = None, None, None, None
     src_sha = kernel_source_sha()
-    for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+    for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if args.workload == "vardct4k" and epf_iters == 2 and args.mix == "default" and os.path.exists(tpath):
             try:
@@ -494,6 +549,12 @@ def main():
         line["untimed"] = e2e
     if gather:
         line["gather"] = gather
+    if (not args.no_also and world == 1 and not use_dist and args.workload == "vardct4k" and args.mix == "default" and args.epf_iters == 2
+            and not args.size and args.stages == 31 and not args.batch):
+        # the contexts of the headline are released first: the side runs get the device to themselves
+        for c in ctxs:
+            c.close()
+        line["also"] = also_runs(args)
     emit(line)
     if use_dist:
         dist.destroy_process_group()
@@ -968,13 +1029,15 @@ def bench_modular(args, rank, world, local_rank, torch, dist):
     gbs = bytes_img * fpg * args.steps / elapsed / 1e9
     # HBM bytes of one plan from the PMC passes of tools/profile_modular.sh (carried while the kernels' sources hash to what was profiled)
     mtraffic, mtraffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r5_modular_traffic.json")))
-        if tj.get("kernel_source_sha256") == kernel_source_sha(MODULAR_SOURCES) and args.workload in tj.get("plans", {}):
-            mtraffic = int(tj["plans"][args.workload]["hbm_bytes_per_plan"])
-            mtraffic_src = "profiles/r5_modular_traffic.json"
-    except Exception:
-        pass
+    for name in ("r6_modular_traffic.json", "r5_modular_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if tj.get("kernel_source_sha256") == kernel_source_sha(MODULAR_SOURCES) and args.workload in tj.get("plans", {}):
+                mtraffic = int(tj["plans"][args.workload]["hbm_bytes_per_plan"])
+                mtraffic_src = "profiles/" + name
+                break
+        except Exception:
+            pass
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import pyoracle as orc

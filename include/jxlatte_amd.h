@@ -231,6 +231,15 @@ jxl_status jxl_vardct_coeff_plane_rows(jxl_ctx* ctx, int32_t rows[3]);
  * info[12] = bytes per output sample. Group g of a frame covers Frame.getGroupLocation / getGroupSize (J/frame/Frame.java:767-786):
  * jxl_vardct_group_size gives its width and height per channel. */
 jxl_status jxl_vardct_geometry(jxl_ctx* ctx, int32_t info[13]);
+/* Geometry of the OUTPUT of the open frame (valid from begin_frame on; what jxl_vardct_read_output* / finish_frame write): info[0],
+ * info[1] = width and height of every output plane -- always the full padded frame, also for chroma-subsampled frames (the planes of
+ * jxl_vardct_geometry are the COEFFICIENT planes) --, info[2] = bytes per sample, info[3] = 1 if the three colours are interleaved
+ * into out[0] (JXL_OUT_RGB8 / JXL_OUT_RGB16: rows of 3 * width samples; out[1], out[2] are ignored), info[4] = number of buffers
+ * that must be non-null (1 or 3). A buffer with row stride `s` pixels (>= width) holds
+ *     info[2] * (info[3] ? 3 : 1) * ((info[1] - 1) * s + info[0])   bytes.
+ * Stands for the sizes the reference states implicitly: Frame.buffer[c] = new float[paddedHeight][paddedWidth]
+ * (J/frame/Frame.java:331-340) and PNGWriter's interleaved rows (J/io/PNGWriter.java:191-212). */
+jxl_status jxl_vardct_output_geometry(jxl_ctx* ctx, int32_t info[5]);
 jxl_status jxl_vardct_group_size(jxl_ctx* ctx, int32_t group, int32_t gw[3], int32_t gh[3]);
 jxl_status jxl_vardct_commit_coeffs_i16(jxl_ctx* ctx);
 /* The same pair without the zero-fill (r4): a decoder writes EVERY sample of every group it decodes (HFCoefficients.java:76-138

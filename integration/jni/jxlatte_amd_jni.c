@@ -104,11 +104,13 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_destroy(JNI
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_beginFrame(JNIEnv* e, jobject self, jobject params) {
     jxl_ctx* c = ctx_of(e, self);
     jxl_vardct_params p;
-    if (!params || (*e)->GetDirectBufferCapacity(e, params) < (jlong)sizeof p) {
-        rethrow(e, c, JXL_ERR_INVALID_ARGUMENT);
+    /* (a heap ByteBuffer has no direct address: GetDirectBufferAddress returns NULL for it) */
+    const void* src = params ? (*e)->GetDirectBufferAddress(e, params) : NULL;
+    if (!src || (*e)->GetDirectBufferCapacity(e, params) < (jlong)sizeof p) {
+        bad_arg(e, "jxlatte_amd: beginFrame needs a direct buffer holding jxl_vardct_params");
         return;
     }
-    memcpy(&p, ADDR(params), sizeof p);
+    memcpy(&p, src, sizeof p);
     CHECK(jxl_vardct_begin_frame(c, &p));
 }
 
@@ -284,17 +286,43 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_commitCoeff
 }
 
 JNIEXPORT jobject JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_hostAlloc(JNIEnv* e, jclass k, jlong bytes) {
+    (void)k;
     void* p = jxl_host_alloc((size_t)bytes);
     return p ? (*e)->NewDirectByteBuffer(e, p, bytes) : NULL;
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_hostFree(JNIEnv* e, jclass k, jobject b) {
+    (void)k;
     if (b) jxl_host_free((*e)->GetDirectBufferAddress(e, b));
+}
+
+/* The output buffers of readOutput / readOutputBegin / finishFrame against the library's own numbers (jxl_vardct_output_geometry, r6):
+ * og[1] rows of og[0] pixels -- the full padded frame, also for chroma-subsampled frames --, og[2] bytes per sample, times 3 when the
+ * format interleaves the colours into ox (RGB8 / RGB16: oy and ob may then be null), `stride` pixels apart (>= og[0]).
+ * 0: an exception is pending. */
+static int out_room(JNIEnv* e, jxl_ctx* c, jobject ox, jobject oy, jobject ob, jlong stride) {
+    int32_t og[5];
+    jxl_status st_ = jxl_vardct_output_geometry(c, og);
+    if (st_ != JXL_OK) {
+        rethrow(e, c, st_);
+        return 0;
+    }
+    if (stride < og[0]) { /* the library's own rule (enqueue_output): a row stride is at least a row */
+        bad_arg(e, "jxlatte_amd: output stride shorter than a row");
+        return 0;
+    }
+    const jlong need = (jlong)og[2] * (og[3] ? 3 : 1) * ((jlong)(og[1] - 1) * stride + og[0]);
+    if (!has_room(e, ox, need) || (og[4] == 3 && (!has_room(e, oy, need) || !has_room(e, ob, need)))) {
+        bad_arg(e, "jxlatte_amd: output buffer missing or too small");
+        return 0;
+    }
+    return 1;
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_finishFrame(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
         jlong stride) {
     jxl_ctx* c = ctx_of(e, self);
+    if (!out_room(e, c, ox, oy, ob, stride)) return;
     void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
     CHECK(jxl_vardct_finish_frame(c, out, stride));
 }
@@ -307,19 +335,7 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_run(JNIEnv*
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
         jlong stride) {
     jxl_ctx* c = ctx_of(e, self);
-    int32_t geo[13];
-    CHECK(jxl_vardct_geometry(c, geo));
-    {   /* H rows of W samples of the output sample size, `stride` samples apart (0: tightly packed) */
-        const jlong st = stride > 0 ? stride : geo[0];
-        if (st < geo[0]) {
-            bad_arg(e, "jxlatte_amd: readOutput stride shorter than a row");
-            return;
-        }
-        const jlong need = (jlong)geo[12] * ((jlong)(geo[3] - 1) * st + geo[0]);
-        NEED(ox, need);
-        NEED(oy, need);
-        NEED(ob, need);
-    }
+    if (!out_room(e, c, ox, oy, ob, stride)) return;
     void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
     CHECK(jxl_vardct_read_output(c, out, stride));
 }
@@ -328,19 +344,7 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutput(
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_readOutputBegin(JNIEnv* e, jobject self, jobject ox, jobject oy, jobject ob,
         jlong stride) {
     jxl_ctx* c = ctx_of(e, self);
-    int32_t geo[13];
-    CHECK(jxl_vardct_geometry(c, geo));
-    {   /* H rows of W samples of the output sample size, `stride` samples apart (0: tightly packed) */
-        const jlong st = stride > 0 ? stride : geo[0];
-        if (st < geo[0]) {
-            bad_arg(e, "jxlatte_amd: readOutputBegin stride shorter than a row");
-            return;
-        }
-        const jlong need = (jlong)geo[12] * ((jlong)(geo[3] - 1) * st + geo[0]);
-        NEED(ox, need);
-        NEED(oy, need);
-        NEED(ob, need);
-    }
+    if (!out_room(e, c, ox, oy, ob, stride)) return;
     void* out[3] = {ADDR(ox), ADDR(oy), ADDR(ob)};
     CHECK(jxl_vardct_read_output_begin(c, out, stride));
 }
@@ -414,6 +418,7 @@ JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_planesDownl
 }
 
 JNIEXPORT void JNICALL Java_com_traneptora_jxlatte_gpu_NativeBackend_runBatch0(JNIEnv* e, jclass k, jlongArray ctxs) {
+    (void)k;
     const jsize n = (*e)->GetArrayLength(e, ctxs);
     jlong h[64];
     jxl_ctx* c[64];

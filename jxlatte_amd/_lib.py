@@ -71,6 +71,7 @@ SIGNATURES = {
     "jxl_vardct_map_coeffs_i16": (i32, [vp, C.POINTER(C.POINTER(C.c_int16)), pi]),
     "jxl_vardct_coeff_plane_rows": (i32, [vp, pi]),
     "jxl_vardct_geometry": (i32, [vp, pi]),
+    "jxl_vardct_output_geometry": (i32, [vp, pi]),
     "jxl_vardct_group_size": (i32, [vp, i32, pi, pi]),
     "jxl_vardct_commit_coeffs_i16": (i32, [vp]),
     "jxl_vardct_map_coeffs_i16_ex": (i32, [vp, C.POINTER(C.POINTER(C.c_int16)), pi, i32]),

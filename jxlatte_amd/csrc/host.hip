@@ -364,18 +364,32 @@ __global__ __launch_bounds__(256) void k_copy16(const v4i_cp* __restrict__ src, 
 }
 
 // queue dst[0, bytes) = src[0, bytes) on the context's stream as a launch of k_copy16; the host side (dst if dst_is_host, else src)
-// must be page-locked and both sides 16-byte aligned. false: not possible (pageable memory) -- the caller takes the runtime's copy
-bool copy_zero(jxl_ctx* c, void* dst, const void* src, size_t bytes, bool dst_is_host, int grid) {
-    if (!bytes || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return false;
+// must be page-locked and both sides 16-byte aligned. Returns 1: queued; 0: not possible (pageable memory, unaligned, or the extent
+// of a caller's buffer cannot be established) -- the caller takes the runtime's copy, which checks the range itself; -1: the
+// page-locked allocation is SHORTER than the transfer (r6: a kernel writing through the device alias past the end of a registration is
+// a GPU page fault that kills the process, where hipMemcpyAsync returned an error -- the library's own staging buffers skip the
+// look-up, `caller_buffer` = false).
+int copy_zero(jxl_ctx* c, void* dst, const void* src, size_t bytes, bool dst_is_host, int grid, bool caller_buffer) {
+    if (!bytes || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return 0;
     void* alias = nullptr;
     if (hipHostGetDevicePointer(&alias, const_cast<void*>(dst_is_host ? dst : src), 0) != hipSuccess || !alias) {
         (void)hipGetLastError();
-        return false;
+        return 0;
+    }
+    if (caller_buffer) {
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)alias) != hipSuccess || !base || !size) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        const uintptr_t lo = (uintptr_t)base, hi = lo + size, a0 = (uintptr_t)alias;
+        if (a0 < lo || a0 + bytes > hi) return -1;
     }
     const size_t n16 = bytes >> 4;
     hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((size_t)grid, (n16 + 255) / 256 + 1)), dim3(256), 0, c->stream,
                        static_cast<const v4i_cp*>(dst_is_host ? src : alias), static_cast<v4i_cp*>(dst_is_host ? alias : dst), n16, bytes & 15);
-    return true;
+    return 1;
 }
 
 // How many workgroups a bus transfer of this context gets. One bounded launch per direction moves 45-57 GB/s each way; many
@@ -792,7 +806,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
     mark("staging");
     if (!c->tab_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->tab_ev, hipEventDisableTiming));
     static const bool tab_zero = !(getenv("JXL_TABLE_ZEROCOPY") && atoi(getenv("JXL_TABLE_ZEROCOPY")) == 0);
-    if (!(tab_zero && c->h_tab_pinned && copy_zero(c, c->tab.p, c->h_tab, total, false, 64)))
+    if (!(tab_zero && c->h_tab_pinned && copy_zero(c, c->tab.p, c->h_tab, total, false, 64, false) == 1))
         HIP_TRY(c, hipMemcpyAsync(c->tab.p, c->h_tab, total, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(c->tab_ev, c->stream));
     c->tab_inflight = true;
@@ -1717,6 +1731,22 @@ jxl_status jxl_vardct_geometry(jxl_ctx* c, int32_t info[13]) {
     return JXL_OK;
 }
 
+jxl_status jxl_vardct_output_geometry(jxl_ctx* c, int32_t info[5]) {
+    if (!c) return JXL_ERR_INVALID_ARGUMENT;
+    if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
+    if (!info) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null argument");
+    // what run_frame will decide (do_out) -- the same expression, so that the numbers hold before and after jxl_vardct_run
+    const jxl_vardct_params& p = c->p;
+    const bool do_out = (p.stages & JXL_STAGE_OUT) && (p.transfer != JXL_TRANSFER_NONE || p.out_format != JXL_OUT_F32);
+    const bool il = do_out && out_interleaved(p.out_format);
+    info[0] = c->W;
+    info[1] = c->H;
+    info[2] = do_out ? out_elem_size(p.out_format) : 4;
+    info[3] = il ? 1 : 0;
+    info[4] = il ? 1 : 3;
+    return JXL_OK;
+}
+
 jxl_status jxl_vardct_group_size(jxl_ctx* c, int32_t group, int32_t gw[3], int32_t gh[3]) {
     if (!c) return JXL_ERR_INVALID_ARGUMENT;
     if (!c->frame_open) return fail(c, JXL_ERR_STATE, "begin_frame first");
@@ -1742,7 +1772,9 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
     static const bool zero_copy = !(getenv("JXL_COMMIT_ZEROCOPY") && atoi(getenv("JXL_COMMIT_ZEROCOPY")) == 0);
     void* hdev = nullptr;
     bool all8 = true;
-    for (int ch = 0; ch < 3; ch++) all8 = all8 && (((c->W >> c->sx[ch]) & 7) == 0);
+    // (the zero-copy widening kernel walks whole 8x8 cells: plane width AND height -- a subsampled plane of a frame whose padded height
+    // is 8 has 4 rows -- must be multiples of 8 and not empty; otherwise the staged path, which handles partial cells)
+    for (int ch = 0; ch < 3; ch++) all8 = all8 && (((c->W >> c->sx[ch]) & 7) == 0) && (((c->H >> c->sy[ch]) & 7) == 0) && (c->H >> c->sy[ch]) >= 8;
     const bool zc = zero_copy && all8 && hipHostGetDevicePointer(&hdev, c->h_map16, 0) == hipSuccess && hdev;
     if (!zc) (void)hipGetLastError();
     for (int ch = 0; ch < 3; ch++) {
@@ -2362,10 +2394,10 @@ int32_t jxl_vardct_last_launch_count(const jxl_ctx* c) { return c ? c->last_laun
 
 // r5: a result buffer in page-locked memory is written by a kernel over PCIe (copy_zero, above) instead of through hipMemcpyAsync.
 // JXL_OUTPUT_ZEROCOPY=0: the runtime's copy.
-static bool copy_out_zero(jxl_ctx* c, void* dst, const void* src, size_t bytes) {
+static int copy_out_zero(jxl_ctx* c, void* dst, const void* src, size_t bytes) {
     static const bool on = !(getenv("JXL_OUTPUT_ZEROCOPY") && atoi(getenv("JXL_OUTPUT_ZEROCOPY")) == 0);
     static const int grid_env = getenv("JXL_OUTPUT_GRID") ? std::max(1, atoi(getenv("JXL_OUTPUT_GRID"))) : 0;
-    return on && copy_zero(c, dst, src, bytes, true, grid_env ? grid_env : bus_grid(c, true));
+    return on ? copy_zero(c, dst, src, bytes, true, grid_env ? grid_env : bus_grid(c, true), true) : 0;
 }
 
 // the copies of the last run's result planes to the host, queued on the context's stream
@@ -2379,8 +2411,9 @@ static jxl_status enqueue_output(jxl_ctx* c, void* const out[3], int64_t out_str
     if (c->result_interleaved) {  // one buffer, rows of 3*W samples; out_stride counts pixels
         if (!out[0]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output buffer");
         if (dense) {
-            if (!copy_out_zero(c, out[0], c->result[0], (size_t)c->W * 3 * es * c->H))
-                HIP_TRY(c, hipMemcpyAsync(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost, c->stream));
+            const int z = copy_out_zero(c, out[0], c->result[0], (size_t)c->W * 3 * es * c->H);
+            if (z < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "page-locked output buffer is shorter than the frame (%zu bytes)", (size_t)c->W * 3 * es * c->H);
+            if (!z) HIP_TRY(c, hipMemcpyAsync(out[0], c->result[0], (size_t)c->W * 3 * es * c->H, hipMemcpyDeviceToHost, c->stream));
         } else HIP_TRY(c, hipMemcpy2DAsync(out[0], (size_t)out_stride * 3 * es, c->result[0], (size_t)c->W * 3 * es, (size_t)c->W * 3 * es, c->H,
                                          hipMemcpyDeviceToHost, c->stream));
         return JXL_OK;
@@ -2388,8 +2421,9 @@ static jxl_status enqueue_output(jxl_ctx* c, void* const out[3], int64_t out_str
     for (int i = 0; i < 3; i++) {
         if (!out[i]) return fail(c, JXL_ERR_INVALID_ARGUMENT, "null output plane %d", i);
         if (dense) {
-            if (!copy_out_zero(c, out[i], c->result[i], (size_t)c->W * es * c->H))
-                HIP_TRY(c, hipMemcpyAsync(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost, c->stream));
+            const int z = copy_out_zero(c, out[i], c->result[i], (size_t)c->W * es * c->H);
+            if (z < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "page-locked output plane %d is shorter than the frame (%zu bytes)", i, (size_t)c->W * es * c->H);
+            if (!z) HIP_TRY(c, hipMemcpyAsync(out[i], c->result[i], (size_t)c->W * es * c->H, hipMemcpyDeviceToHost, c->stream));
         } else HIP_TRY(c, hipMemcpy2DAsync(out[i], (size_t)out_stride * es, c->result[i], (size_t)c->W * es, (size_t)c->W * es, c->H,
                                          hipMemcpyDeviceToHost, c->stream));
     }

@@ -406,6 +406,7 @@ def make_modular_frame(width, height, channels=3, seed=7, sp=None, res_scale=4.0
         if i < channels:
             a = rng.integers(0, 256, size=(h, w)).astype(np.int32)
         else:
-            a = np.rint(rng.laplace(0.0, res_scale, size=(h, w))).astype(np.int32)
+            # (clipped BEFORE the cast: a float outside int32 converts to a platform-defined value, and the fuzz's wide res_scale reaches it)
+            a = np.clip(np.rint(rng.laplace(0.0, res_scale, size=(h, w))), -2147483648.0, 2147483647.0).astype(np.int64).astype(np.int32)
         chans.append(np.ascontiguousarray(a))
     return dict(chans=chans, sp=sp, shapes=enc, width=width, height=height, channels=channels, seed=seed)

@@ -114,3 +114,19 @@ def test_8k_modular_segmented_equals_serial_walk(ctx, monkeypatch):
     for mode in ("lds", "hybrid", "walk"):
         for a, b in zip(outs[mode], outs["serial"]):
             assert a.shape == (4320, 7680) and np.array_equal(a, b), mode
+
+
+def test_8k_modular_default_plan_vs_oracle(ctx, orc):
+    """north_star's 8K Modular size against the ORACLE (ModularChannel.java:361-413 over the default plan of
+    ModularStream.java:110-131,229-254), not only against the device's own serial walk: 7680 x 4320 x 3, seed 7, the library's own
+    segment / chunk-width choice (k_inv_vh32 at a pitch that is a multiple of 128 bytes -- where kVhPad's line alignment bites and where
+    the r5 store-data hazard showed first). Twice: that hazard was run-to-run."""
+    mod = synth.make_modular_frame(7680, 4320, channels=3, seed=7)
+    exp = orc.modular_apply(mod["chans"], mod["sp"])
+    ms = host.ModularStream(ctx, mod["chans"], mod["sp"])
+    for rep in range(2):
+        got = ms.applyTransforms()
+        assert len(got) == len(exp) == 3
+        for i, (a, b) in enumerate(zip(got, exp)):
+            assert a.shape == b.shape == (4320, 7680)
+            assert np.array_equal(a, b), "8K modular channel %d (run %d): %d samples differ" % (i, rep, int((a != b).sum()))

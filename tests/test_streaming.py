@@ -68,6 +68,34 @@ def test_page_locked_output_is_written_by_a_kernel_and_equals_the_runtime_copy(s
 
 
 @pytest.mark.gpu
+def test_page_locked_output_shorter_than_the_frame_is_an_error_not_a_fault():
+    """r6: copy_zero writes a page-locked destination through its device alias with a kernel; it now looks up the
+    extent of the allocation first (hipMemGetAddressRange) and a destination SHORTER than the frame is JXL_ERR_INVALID_ARGUMENT -- not a
+    GPU page fault past the end of the registration --, for read_output and read_output_begin alike. The context stays usable."""
+    lib = _lib.load()
+    fr, p = _frame(520, 264, 91, abi.OUT_F32)
+    with _lib.Context(0) as ctx:
+        f, exp = _sync_output(ctx, fr, p)
+        plane = exp[0].nbytes
+        short = host.PinnedArray(lib, (3 * plane - 4096,), np.uint8)  # three planes carved from one allocation; the last one is 4 KB short
+        full = host.PinnedArray(lib, exp.shape, exp.dtype)
+        try:
+            pp = (C.c_void_p * 3)(*[short.array.ctypes.data + c * plane for c in range(3)])
+            with pytest.raises(_lib.IllegalArgumentException):
+                ctx.call("jxl_vardct_read_output", pp, f.width)
+            with pytest.raises(_lib.IllegalArgumentException):
+                ctx.call("jxl_vardct_read_output_begin", pp, f.width)
+            ctx.synchronize()
+            pq = (C.c_void_p * 3)(*[full.array[c].ctypes.data for c in range(3)])
+            ctx.call("jxl_vardct_read_output", pq, f.width)
+            assert np.array_equal(full.array.view(np.uint32), exp.view(np.uint32))
+        finally:
+            ctx.synchronize()
+            short.free()
+            full.free()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_ctx,fpc", [(1, 2), (3, 4)])
 def test_native_stream_harness_streams_identical_frames(n_ctx, fpc):
     """bench.py's streaming leg at a small size: every context's last frame equals the synchronous path's pixels"""
