@@ -2,6 +2,7 @@
 // varblock binning and the launch sequence. gfx950 only; there is no CPU fallback -- every entry
 // point needs a HIP device and fails with JXL_ERR_DEVICE otherwise.
 #include "jxl_internal.h"
+#include "modular_tend.h"  // kSqueezeSafeIn (jxl_modular_begin picks the plan by it)
 
 #include <algorithm>
 #include <chrono>
@@ -403,6 +404,11 @@ int bus_grid(const jxl_ctx* c, bool out) {
     return n <= 2 ? 128 : std::max(out ? 16 : 32, (out ? 128 : 256) / n);
 }
 
+// three EPF iterations as two launches (run_frame; JXL_EPF3_SPLIT=0: one launch)
+bool epf3_split_on() {
+    static const bool v = !(getenv("JXL_EPF3_SPLIT") && atoi(getenv("JXL_EPF3_SPLIT")) == 0);
+    return v;
+}
 bool is_small(int t) { return JXL_TT[t].ph == 8 && JXL_TT[t].pw == 8; }
 bool is_large(int t) { return JXL_TT[t].ph >= 128 || JXL_TT[t].pw >= 128; }
 
@@ -652,6 +658,9 @@ jxl_status finalize_tables(jxl_ctx* c) {
         // subsampled frames, whose channels have their own geometry)
         static const bool use_wg3 = !(getenv("JXL_IDCT_WG3") && atoi(getenv("JXL_IDCT_WG3")) == 0);
         jxl_ctx::TypeLaunch cl[4] = {{3, channel, {}}, {2, channel, {}}, {1, channel, {}}, {0, channel, {}}};  // launch order: heaviest class first
+        // r6: the special 8x8 types of a frame without chroma subsampling are items of the persistent launch too (wg3_special_items):
+        // they join class 2's segments and get no launch of their own below
+        const bool special_in_wg3 = use_wg3 && channel < 0 && wg3_special_items();
         for (int t : kOrder) {
             if (lists[t].empty()) continue;
             const IdctSegment sg{t, (int)first_of[t], (int)lists[t].size()};
@@ -659,9 +668,15 @@ jxl_status finalize_tables(jxl_ctx* c) {
             for (auto& l : cl)
                 if (l.cls == cls) l.segs.push_back(sg);
         }
+        if (special_in_wg3)
+            for (int t : kSpecial) {
+                if (lists[t].empty() || !wg3_handles(t)) continue;
+                for (auto& l : cl)
+                    if (l.cls == 2) l.segs.push_back(IdctSegment{t, (int)first_of[t], (int)lists[t].size()});
+            }
         for (auto& l : cl) {
             // the launch argument blocks hold kMaxSeg segments (one per type of a class): checked HERE, where the lists are made
-            if (l.segs.size() > (size_t)std::min(MultiArgs::kMaxSeg, Wg3Args::kMaxSeg)) seg_overflow = true;
+            if (l.segs.size() > (size_t)(l.cls >= 2 ? Wg3Args::kMaxSeg : MultiArgs::kMaxSeg)) seg_overflow = true;
             if (!l.segs.empty()) c->type_launches.push_back(std::move(l));
         }
         jxl_ctx::SpecialLaunch sl{(int)items.size(), 0, channel, false};
@@ -680,7 +695,7 @@ jxl_status finalize_tables(jxl_ctx* c) {
         static const bool special_wg = !(getenv("JXL_SPECIAL_WG") && atoi(getenv("JXL_SPECIAL_WG")) == 0);
         const bool wg_items = channel < 0 && special_wg;
         for (int t : kSpecial)
-            for (uint32_t o = 0; o < lists[t].size(); o += 64)
+            for (uint32_t o = 0; o < (special_in_wg3 && wg3_handles(t) ? 0u : (uint32_t)lists[t].size()); o += 64)
                 for (uint32_t ch = ch0; ch < (wg_items ? ch0 + 1 : ch1); ch++) {
                     const DevBlock& b0 = lists[t][o];
                     ord.push_back(Ord{(uint32_t)((b0.cy >> 5) * grs_c + (b0.cx >> 5)),
@@ -2063,8 +2078,7 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
         // window of a 58x26 output tile (1.36 x its pixels) and its 118 registers hold ALL stages of the kernel to 2 workgroups
         // per CU; split, it runs once per pixel, and the second launch is the 63-register kernel at 4 workgroups per CU. The
         // planes cross HBM once more (200 MB per 4K frame, under the launches' arithmetic). JXL_EPF3_SPLIT=0: one launch.
-        static const bool epf3_split = !(getenv("JXL_EPF3_SPLIT") && atoi(getenv("JXL_EPF3_SPLIT")) == 0);
-        const bool split = epf3_split && rp.epf_iters == 3 && c->W >= 8 && c->H >= 8;
+        const bool split = epf3_split_on() && rp.epf_iters == 3 && c->W >= 8 && c->H >= 8;
         if (collect && split) {
             if (collected) *collected = false;  // (jxl_vardct_run_batch: this frame launches its own pair)
             return JXL_OK;
@@ -2337,7 +2351,15 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
     std::vector<FusedArgs> fa((size_t)n);
     bool all = batch_restore;
     for (int i = 0; i < n; i++) all = all && ctxs[i]->W >= 8 && ctxs[i]->H >= 8;  // what the fused kernel covers: in collect
-    if (all) {                                                                     // mode such a frame enqueues nothing
+                                                                                   // mode such a frame enqueues nothing
+    // r6: a frame with three EPF iterations launches its own pair of kernels (epf3_split_on): decided HERE, before any
+    // frame's collect pass -- run_frame(collect) used to return early for such a frame after its bookkeeping, and the collect passes
+    // of the frames in front of it were thrown away
+    for (int i = 0; i < n && all; i++) {
+        const jxl_vardct_params& q = ctxs[i]->p;
+        if (epf3_split_on() && (q.stages & JXL_STAGE_EPF) && q.epf_iters == 3) all = false;
+    }
+    if (all) {
         for (int i = 0; i < n && all; i++) {
             bool got = false;
             const jxl_status st = run_frame(ctxs[i], true, &fa[(size_t)i], &got);  // bookkeeping + argument block, no launch
@@ -3201,10 +3223,24 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
         }
     }
     std::vector<ModChan> ch;
+    // r6: the fused V + H kernel carries only the short tendency() form (exact while |sample| < 2^23, modular_tend.h); a
+    // plan whose inputs are outside that range -- high-bit-depth or float-as-int channels -- would run fused once, report, and be run
+    // again step by step (mod_settle). A sparse scan of the uploaded channels (every 16th row: ~2 ms of host time for an 8K image)
+    // picks the step-by-step plan up front for such inputs. Only a choice of plan: the device check is what guarantees the result.
+    bool wide_samples = false;
     for (int i = 0; i < n_chans; i++) {
         if (chans[i].width < 0 || chans[i].height < 0) return fail(c, JXL_ERR_INVALID_ARGUMENT, "negative channel size");
         const size_t n = (size_t)chans[i].width * chans[i].height;
         if (n && !chans[i].data) return fail(c, JXL_ERR_INVALID_ARGUMENT, "channel %d has no data", i);
+        for (int y = 0; y < chans[i].height && !wide_samples; y += 16) {
+            const int32_t* row = chans[i].data + (size_t)y * chans[i].width;
+            int32_t lo = 0, hi = 0;
+            for (int x = 0; x < chans[i].width; x++) {
+                lo = std::min(lo, row[x]);
+                hi = std::max(hi, row[x]);
+            }
+            wide_samples = lo <= -kSqueezeSafeIn || hi >= kSqueezeSafeIn;
+        }
         int32_t* d = alloc_pad(n, is_hres[i] ? kVhPadH : kVhPad);
         if (!d) return fail(c, JXL_ERR_OOM, "device allocation failed (modular channel)");
         if (n) HIP_TRY(c, hipMemcpy(d, chans[i].data, 4 * n, hipMemcpyHostToDevice));
@@ -3341,7 +3377,7 @@ jxl_status jxl_modular_begin(jxl_ctx* c, const jxl_channel* chans, int32_t n_cha
     c->mod_out = ch;
     // r5: every V step followed by the H step of the same channels becomes one launch (k_modular_vh.hip)
     c->mod_ops_fused.clear();
-    if (!getenv("JXL_SQUEEZE_NO_VH")) {
+    if (!getenv("JXL_SQUEEZE_NO_VH") && !wide_samples) {
         bool any = false;
         for (size_t i = 0; i < c->mod_ops.size();) {
             if (i + 1 < c->mod_ops.size() && squeeze_pair_fusable(c->mod_ops[i], c->mod_ops[i + 1])) {

@@ -112,7 +112,7 @@ struct IdctSegment { int type, first_block, n_blocks; };
 // Argument block of the persistent three-channel IDCT launch (k_idct_wg3.hip): type-uniform segments in launch order
 struct Wg3Seg { int type, first_block, n_blocks, item_base; };  // item_base: index of the segment's first work item in the launch
 struct Wg3Args {
-    static constexpr int kMaxSeg = 12;
+    static constexpr int kMaxSeg = 21;
     DevFrame f;
     const DevBlock* blocks;
     float *o0, *o1, *o2;
@@ -124,11 +124,13 @@ struct Wg3Args {
     const int* items;
     Wg3Seg seg[kMaxSeg];
 };
+
 // the item list of one class's segments in spatial order, dealt to the XCDs in runs (host side)
 void wg3_item_table(const DevBlock* host_blocks, int frame_bw, const IdctSegment* segs, int n_seg, int which, const int32_t* woffs, bool spatial,
                     std::vector<int>& out, int grid);
 int wg3_grid_cap(bool big);  // workgroups of a single-frame launch (JXL_WG3_GRID / JXL_WG3_GRID_BIG)
 bool wg3_handles(int type);
+bool wg3_special_items();  // r6: the special 8x8 types are items of the persistent launch
 bool wg3_big(int type);  // the 64-point family: its own launch (register / LDS class)
 bool wg3_llf_in_item();  // finalizeLLF inside the k_idct_wg3 items (default) or as a launch of its own writing the llf planes
 int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment* segs, int n_seg, int which, float* const out[3],

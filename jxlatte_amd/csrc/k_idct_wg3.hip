@@ -39,6 +39,8 @@
 
 namespace jxl {
 
+#include "idct_small.h"
+
 namespace {
 
 // Two adjacent outputs of a lane. JXL_WG3_SCALAR_MAC: a plain pair of floats instead of the 2-vector the packed instructions
@@ -139,17 +141,20 @@ struct Cls {
     static constexpr int WS = BIG ? NG : 1;
 };
 
-template <int H, int W>
+// LD_ / IMG_ (r6): row stride and size of a block image when they are not the transform passes' own (0: LD = W + 1 and the bank-staggered
+// IMG below) -- the special 8x8 types keep their blocks as 64 consecutive floats at an odd pitch of 65, so that the lane that transforms
+// block-channel k in registers reads image k without bank conflicts.
+template <int H, int W, int LD_ = 0, int IMG_ = 0>
 struct Cfg {
     static constexpr int MAXD = H > W ? H : W;
     static constexpr bool BIG = MAXD > 32;
     static constexpr int T = Cls<BIG>::T;
     static constexpr int P = MAXD <= 32 ? 2048 : 4096;  // sample positions per channel and work item
     static constexpr int NB = P / (H * W);               // varblocks per work item
-    static constexpr int LD = W + 1;                     // row stride of a block image (odd: rows hit different banks)
+    static constexpr int LD = LD_ ? LD_ : W + 1;         // row stride of a block image (odd: rows hit different banks)
     static constexpr int IMG0 = H * LD;
     // consecutive blocks of a column-pass wave land on consecutive bank ranges: image size == W (mod 32) for W < 32
-    static constexpr int IMG = W >= 32 ? IMG0 : IMG0 + ((W - IMG0 % 32) + 32) % 32;
+    static constexpr int IMG = IMG_ ? IMG_ : W >= 32 ? IMG0 : IMG0 + ((W - IMG0 % 32) + 32) % 32;
     static constexpr int GPB = H * W / 4;                // 4-sample groups per block
     static constexpr int NG = P / 4 / T;                 // groups per lane and channel
     static constexpr int WS = Cls<BIG>::WS;
@@ -332,8 +337,9 @@ struct Item {
 __host__ __device__ inline uint32_t wg3_geo(int type) {
     const int H = JXL_TT[type].ph, W = JXL_TT[type].pw;
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) l++; return l; };
+    // (TransformType.flip(): tall, or square AND METHOD_DCT -- the special 8x8 types are square and not flipped)
     return (uint32_t)lg(W / 4) | (uint32_t)lg(H * W / 4) << 4 | (uint32_t)lg((H / 8) * (W / 8)) << 8 | (uint32_t)lg(W / 8) << 12 |
-           (H >= W ? 1u << 15 : 0u) | (uint32_t)JXL_TT[type].param_index << 16;
+           ((H > W || (H == W && JXL_TT[type].method == JXL_METHOD_DCT)) ? 1u << 15 : 0u) | (uint32_t)JXL_TT[type].param_index << 16;
 }
 
 // Item gi of the launch: ONE 32-byte record {type, first block, blocks, geometry word, weight offsets of the three channels, 0}
@@ -491,9 +497,9 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
     }
 }
 
-template <int H, int W, int TYPE>
+template <int H, int W, int TYPE, int LD_ = 0, int IMG_ = 0>
 struct Body {
-    using C = Cfg<H, W>;
+    using C = Cfg<H, W, LD_, IMG_>;
 
     // ---- A. dequantise + chroma-from-luma -> LDS
     static __device__ __forceinline__ void dequant(const Wg3Args& a, const Item& it, int tid, const Raw<C::NG, C::WS>& raw, float* __restrict__ img,
@@ -660,6 +666,72 @@ struct Body {
     }
 };
 
+// ---- r6: the 8x8-footprint types that are not METHOD_DCT -- Hornuss, DCT2, DCT4, DCT4x8, DCT8x4, AFV0-3 (PassGroup.java:88-168, 234-325)
+// -- as items of this launch (32 blocks x 3 channels, the geometry of an 8x8 DCT item: same requests, same dequantisation, same store
+// mapping; only the weights are the untransposed ones, TransformType.flip() being false for them). Until r6 a launch of their own on a
+// side stream (k_idct_special_wg): 17 us alone for 12 % of the pixels of the default mix, and in the saturated regime -- eight frames in
+// flight, where `value` is measured -- a second launch per frame costs the stage 11-19 us per frame however the streams are mapped
+// (profiles/experiments/r6_idct_saturated_mixes_r5kernels.txt: 88 % DCT8 + 12 % AFV0 61 us per frame, either type alone 40-42).
+// Transform: lane (channel, block) holds the block's 64 pixels in registers and reads its coefficients from the image as it goes
+// (idct_small.h); 96 of 256 lanes work in that phase.
+using SpecialBody = Body<8, 8, 0, 8, 65>;
+__host__ __device__ constexpr bool wg3_is_special(int type) { return (type >= 1 && type <= 3) || (type >= 12 && type <= 17); }
+
+// The transform of one block of one channel, image at lds[off .. off + 64), in place. NOT inlined on purpose: its 64 + 64 registers sit
+// on top of whatever the item loop keeps alive; inlined, the allocator answered with 112 spilled registers whose reloads landed in
+// EVERY type's passes (9 scratch accesses per body); as a call, the registers the callee has to preserve are saved and restored in its
+// own prologue and epilogue -- paid by the special items only. `off` instead of a pointer keeps the LDS address space (a generic
+// pointer would turn the accesses into flat_* ones).
+__device__ __attribute__((noinline)) void special_transform(int off, int type) {
+    extern __shared__ float lds[];
+    float* im = lds + off;
+    float px[64];
+    switch (type) {
+    case 1: invert_small<1>(im, px); break;
+    case 2: invert_small<2>(im, px); break;
+    case 3: invert_small<3>(im, px); break;
+    case 12: invert_small<12>(im, px); break;
+    case 13: invert_small<13>(im, px); break;
+    case 14: invert_small<14>(im, px); break;
+    case 15: invert_small<15>(im, px); break;
+    case 16: invert_small<16>(im, px); break;
+    case 17: invert_small<17>(im, px); break;
+    default: break;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++) im[i] = px[i];
+}
+
+// the transform phase of a special item: between the item's dequantisation and the requests of the next item (wg3_body)
+__device__ __forceinline__ void special_phase(const Item& it, int tid) {
+    using C = SpecialBody::C;
+    if (tid < 3 * C::NB && (tid & (C::NB - 1)) < it.nb) special_transform(tid * C::IMG, it.type);  // image index (channel * NB + block) == lane
+    lds_barrier();
+}
+
+// ... and its stores: lane -> (block, row), as in the row pass of an 8x8 DCT item (Raw::rowx is that block's record)
+template <typename PreStore>
+__device__ __forceinline__ void special_store(const Wg3Args& a, const Item& it, int tid, const float* __restrict__ img, int rowx, PreStore pre_store) {
+    using C = SpecialBody::C;
+    const int rb = tid >> 3, ry = tid & 7;
+    // The next item's requests went out between the transform and here (not before the transform: their 45 registers would sit on
+    // top of the block's 64 + 64), i.e. ahead of these stores: the wait for them below (vmcnt counts in order) does not wait for the
+    // stores, and what is exposed of their latency is paid once per special item. wg3_item_table puts the special items last.
+    if (rb < it.nb) {
+        const DevFrame& f = a.f;
+        float* o3[3] = {a.o0, a.o1, a.o2};
+        const int cy = (int)((uint32_t)rowx & 0xffffu), cx = (int)((uint32_t)rowx >> 16);
+        const int64_t off = (int64_t)(cy * 8 + ry) * f.width + cx * 8;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float* sp = img + (ch * C::NB + rb) * C::IMG + ry * 8;
+            *reinterpret_cast<float4*>(o3[ch] + off) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+            *reinterpret_cast<float4*>(o3[ch] + off + 4) = make_float4(sp[4], sp[5], sp[6], sp[7]);
+        }
+    }
+    pre_store();  // the next item's loads have landed; its LF patches are published (the barrier at the end of the item loop follows)
+}
+
 // type dispatch of the two specialised phases (workgroup-uniform scalar branch)
 template <bool BIG>
 __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int tid, const Raw<Cls<BIG>::NG, Cls<BIG>::WS>& raw, float* img,
@@ -682,7 +754,7 @@ __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int
         case 9: Body<8, 32, 9>::dequant(a, it, tid, raw, img, qtab); break;
         case 10: Body<32, 16, 10>::dequant(a, it, tid, raw, img, qtab); break;
         case 11: Body<16, 32, 11>::dequant(a, it, tid, raw, img, qtab); break;
-        default: __builtin_unreachable();  // item_of hands out the types of this class only
+        default: SpecialBody::dequant(a, it, tid, raw, img, qtab); break;  // (item_of hands out the types of this class only)
         }
     }
 }
@@ -706,7 +778,7 @@ __device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int 
         case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
-        default: __builtin_unreachable();  // item_of hands out the types of this class only
+        default: special_store(a, it, tid, img, rowx, pre_store); break;  // (item_of hands out the types of this class only)
         }
     }
 }
@@ -732,10 +804,10 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     extern __shared__ float lds[];
     const int tid0 = threadIdx.x;
     const int G = (int)gridDim.x;
-    int gi = (int)blockIdx.x;
 #ifdef JXL_IDCT_PRIO
     __builtin_amdgcn_s_setprio(JXL_IDCT_PRIO);
 #endif
+    int gi = (int)blockIdx.x;
     Item cur = item_of<P>(a, gi);
     if (cur.type < 0) return;
     STAMP3_LIFE(0, __builtin_amdgcn_s_memtime());
@@ -800,7 +872,16 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         lds_barrier();
         STAMP3(2);
         // everything the next item needs from memory: in flight during both passes of this one. Its block records were
-        // requested one item earlier still, so no load here waits for another.
+        // requested one item earlier still, so no load here waits for another. (A special 8x8 item issues them between its transform
+        // and its stores instead: special_passes.)
+        // a special 8x8 item transforms its blocks first (lane = block of one channel, in registers: special_transform); the registers
+        // of the item's own requests are dead by now, and those of the next item's are not in use yet
+        if (!BIG && wg3_is_special(cur.type)) {
+            // (the 256-thread class's prefetch leaves the registers of groups outside an item alone, i.e. the old values stay live
+            // across the call below: ended here -- 45 v_mov per special item)
+            raw = Raw<NG, WS>{};
+            special_phase(cur, tid);
+        }
         prefetch<T, NG, WS>(a, nxt, tid, rc, raw);
         gi += G;
         const Item nn = item_of<P>(a, gi + G);
@@ -902,8 +983,13 @@ bool wg3_handles(int type) {
     if (type < 32 && ((skip >> type) & 1u)) return false;
     switch (type) {
     case 0: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 18: case 19: case 20: return true;
-    default: return false;
+    default: return wg3_special_items() && wg3_is_special(type);
     }
+}
+// r6: the special 8x8 types as items of the persistent launch (JXL_WG3_SPECIAL=0: their own launch on the side stream, as until r5)
+bool wg3_special_items() {
+    static const bool v = !(getenv("JXL_WG3_SPECIAL") && atoi(getenv("JXL_WG3_SPECIAL")) == 0);
+    return v;
 }
 bool wg3_big(int type) { return type == 18 || type == 19 || type == 20; }
 
@@ -922,6 +1008,7 @@ int wg3_blocks_per_item(int type) {
 static int wg3_img_floats(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
     const int nb = wg3_blocks_per_item(type);
+    if (wg3_is_special(type)) return 3 * nb * 65;  // SpecialBody
     const int img0 = h * (w + 1);
     const int img = w >= 32 ? img0 : img0 + ((w - img0 % 32) + 32) % 32;
     return 3 * nb * img;
@@ -940,7 +1027,7 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
     a.img_floats = 0;
     a.items = nullptr;
     a.llf_in_item = wg3_llf_in_item() ? 1 : 0;
-    static_assert(Wg3Args::kMaxSeg >= 12, "one segment per type wg3_handles() accepts (12 types: the LLF launch passes both classes)");
+    static_assert(Wg3Args::kMaxSeg >= 21, "one segment per type wg3_handles() accepts (21 types: the LLF launch passes both classes)");
     for (int i = 0; i < n_seg; i++) {
         if (segs[i].n_blocks <= 0 || !wg3_handles(segs[i].type) || (which != 2 && wg3_big(segs[i].type) != (which == 1))) continue;
         // a type twice in the list, or a new type without a larger kMaxSeg: never drop blocks silently, never kill the host
@@ -976,6 +1063,7 @@ int build_wg3_args(const DevFrame& f, const DevBlock* blocks, const IdctSegment*
 static float wg3_item_cost(int type) {  // us per 4K frame tiled with the type, i.e. relative cost of 2048 positions
     switch (type) {
     case 0: return 55.f;
+    case 1: case 2: case 3: case 12: case 13: case 14: case 15: case 16: case 17: return 70.f;
     case 4: return 76.f;
     case 5: return 100.f;
     case 6: case 7: return 67.f;
@@ -1009,19 +1097,27 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
         for (const Rec& r : recs) emit(r);
         return;
     }
-    std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
+    // r6: the special 8x8 items go BEHIND the others (each part in its own spatial order): such an item issues the next item's requests
+    // only after its transform (special_passes), i.e. the item behind it waits for memory -- at the end of the list that item is another
+    // special one or none (a 4K frame of the default mix has about one special item per workgroup)
+    std::stable_partition(recs.begin(), recs.end(), [](const Rec& r) { return !wg3_is_special(r.type); });
+    const size_t n_normal = (size_t)(std::find_if(recs.begin(), recs.end(), [](const Rec& r) { return wg3_is_special(r.type); }) - recs.begin());
     static const int run = getenv("JXL_WG3_RUN") ? std::max(1, atoi(getenv("JXL_WG3_RUN"))) : 24;
-    std::vector<const Rec*> q[8];
-    for (size_t i = 0; i < recs.size(); i++) q[(i / (size_t)run) % 8].push_back(&recs[i]);
-    size_t longest = 0;
-    for (auto& v : q) longest = std::max(longest, v.size());
     out.clear();
     out.reserve(recs.size() * 8);
     std::vector<const Rec*> lst;
     lst.reserve(recs.size());
-    for (size_t i = 0; i < longest; i++)
-        for (int x = 0; x < 8; x++)
-            if (i < q[x].size()) lst.push_back(q[x][i]);
+    for (int part = 0; part < 2; part++) {
+        const size_t r0 = part == 0 ? 0 : n_normal, r1 = part == 0 ? n_normal : recs.size();
+        std::stable_sort(recs.begin() + (ptrdiff_t)r0, recs.begin() + (ptrdiff_t)r1, [](const Rec& x, const Rec& y) { return x.key < y.key; });
+        std::vector<const Rec*> q[8];
+        for (size_t i = r0; i < r1; i++) q[((i - r0) / (size_t)run) % 8].push_back(&recs[i]);
+        size_t longest = 0;
+        for (auto& v : q) longest = std::max(longest, v.size());
+        for (size_t i = 0; i < longest; i++)
+            for (int x = 0; x < 8; x++)
+                if (i < q[x].size()) lst.push_back(q[x][i]);
+    }
     static const bool balance = !(getenv("JXL_WG3_BALANCE") && atoi(getenv("JXL_WG3_BALANCE")) == 0);
     const size_t N = lst.size(), G = (size_t)std::max(0, grid);
     if (balance && G >= 8 && G % 8 == 0 && N > G) {

@@ -27,7 +27,8 @@ bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h
 
 
 // which kernel instantiation the arguments select: Gaborish on/off, EPF iterations, sink kind
-int restore_fused_variant(const FusedArgs& a) { return (a.p.gab ? 32 : 0) | (a.p.epf_iters & 3) << 3 | sink_kind_of(a.p); }
+// (epf_iters 0..3, or 4 = the 13-tap iteration alone of the two-launch form: three bits)
+int restore_fused_variant(const FusedArgs& a) { return (a.p.gab ? 64 : 0) | (a.p.epf_iters & 7) << 3 | sink_kind_of(a.p); }
 
 // host_args: the n frames' argument blocks (all of one variant), dev_args: the same blocks in device memory
 void launch_restore_fused_batch(const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s) {
@@ -49,7 +50,7 @@ bool launch_restore_fused(const float* const in[3], void* const out[3], int h, i
         // there: 841 us per 4K frame against 259 us with 4x1 patches and a 128-register budget (JXL_RESTORE_PH=2 selects 4x2,
         // float planes only)
         static const int ph_env = getenv("JXL_RESTORE_PH") ? atoi(getenv("JXL_RESTORE_PH")) : 0;
-        if (ph_env == 2) {
+        if (ph_env == 2 && p.epf_iters <= 3) {  // (4 = the 13-tap iteration alone: 4x1 patches only)
             const int it = p.epf_iters;
             if (p.gab) {
                 if (it == 0) launch_tph<true, 0, SK_PLAIN, 2>(a, s);

@@ -7,4 +7,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VA
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --output-format csv --pmc $set -d $R/gpurun_out/pmc_$T/$n -o p -- python3 $R/tools/idct_mix_bench.py $T > /dev/null 2>&1
 done
-cd $R && for f in $(find gpurun_out/pmc_$T -name "*counter_collection.csv"); do python3 tools/pmc_summary.py $f | grep -A1 "k_idct_multi\|k_idct_special"; done
+cd $R && for f in $(find gpurun_out/pmc_$T -name "*counter_collection.csv"); do python3 tools/pmc_summary.py $f | grep -A1 "k_idct"; done
