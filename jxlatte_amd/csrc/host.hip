@@ -1107,6 +1107,34 @@ void build_srgb16_table(float* out) {
 }
 }  // namespace jxl
 
+// Diagnostic (tools/clock_probe.py, r6): the shader clock the chip actually holds while other work runs. One wave on a stream of its
+// own spins for `us` microseconds of s_memrealtime (a constant 100 MHz counter) and reports how many shader cycles (s_memtime) went by:
+// clock = cycles / ticks x 100 MHz (guide, DVFS give-back (6)). Not part of the C-ABI of include/jxlatte_amd.h.
+__global__ void k_clock_probe(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+extern "C" int jxl_debug_clock_probe(int device, double us, double* mhz) {
+    static hipStream_t s = nullptr;
+    static unsigned long long* d = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!d && hipMalloc(&d, 16) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, (unsigned long long)(us * 100.0), d);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -1;
+    *mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    return 0;
+}
 extern "C" void jxl_debug_pq_table(float* out) { jxl::build_pq_table(out); }  // CPU tests: the table without a device
 extern "C" void jxl_debug_pq16_thresholds(float* out) { jxl::build_pq16_thresholds(out); }
 extern "C" void jxl_debug_srgb16_table(float* out) { jxl::build_srgb16_table(out); }
@@ -1921,7 +1949,9 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                 if (tl.cls >= 2) {
                     wn[tl.cls - 2] = build_wg3_args(f, blocks, tl.segs.data(), (int)tl.segs.size(), tl.cls - 2, A, wa[tl.cls - 2]);
                     if (wn[tl.cls - 2] < 0) return fail(c, JXL_ERR_STATE, "IDCT launch: too many segments");
-                    if (c->wg3_item_count[tl.cls - 2] != wn[tl.cls - 2]) return fail(c, JXL_ERR_STATE, "IDCT launch: item list out of date");
+                    // (r6: the list may hold holes -- wg3_item_table --: at least one record per item, and the list's length is what the walk is bounded by)
+                    if (c->wg3_item_count[tl.cls - 2] < wn[tl.cls - 2]) return fail(c, JXL_ERR_STATE, "IDCT launch: item list out of date");
+                    if (wn[tl.cls - 2] > 0) wa[tl.cls - 2].total_items = wn[tl.cls - 2] = c->wg3_item_count[tl.cls - 2];
                     wa[tl.cls - 2].items = c->wg3_items[tl.cls - 2].as<int>();
                     all.insert(all.end(), tl.segs.begin(), tl.segs.end());
                 }
@@ -2273,7 +2303,8 @@ jxl_status jxl_vardct_run_batch(jxl_ctx* const* ctxs, int32_t n) {
                 if (items < 0) return fail(c0, JXL_ERR_STATE, "IDCT launch: too many segments");
                 if (items <= 0) continue;
                 if (cls != 10) {
-                    if (c->wg3_item_count[cls - 11] != items) return fail(c0, JXL_ERR_STATE, "IDCT launch: item list out of date");
+                    if (c->wg3_item_count[cls - 11] < items) return fail(c0, JXL_ERR_STATE, "IDCT launch: item list out of date");
+                    a.total_items = c->wg3_item_count[cls - 11];
                     a.items = c->wg3_items[cls - 11].as<int>();
                 }
                 if (cls == 10) {

@@ -279,6 +279,85 @@ __device__ __forceinline__ void idct1d3(Acc3<KC>& acc, cfloatp lut /* row 0, lan
     }
 }
 
+// The same for ONE channel (r6: a 64x64 block as an item of the 256-thread launch is worked channel by channel, Item64 below): KC
+// outputs per lane, the LUT slice of a step feeds KC / 4 packed multiplies instead of 3 KC / 4.
+template <int KC>
+struct Acc1 {
+    v2f lo[KC / 4], hi[KC / 4];
+    __device__ __forceinline__ void init(float a) {
+#pragma unroll
+        for (int j = 0; j < KC / 4; j++) lo[j] = hi[j] = v2f{a, a};
+    }
+    __device__ __forceinline__ float get(int i) const {
+        if (i < KC / 2) return (i & 1) ? lo[i / 2].y : lo[i / 2].x;
+        const int m = KC - 1 - i;
+        return (m & 1) ? hi[m / 2].y : hi[m / 2].x;
+    }
+};
+template <int KC>
+struct Blk1 {
+    v2f l[4][KC / 4];
+    float s[4];
+};
+template <int KC>
+__device__ __forceinline__ void load_blk1(Blk1<KC>& b, cfloatp lut /* row n0-1, the lane group's slice */, int N, const float* p0, int stride) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const cfloatp lr = lut + u * N;
+#pragma unroll
+        for (int j = 0; j < KC / 4; j++) b.l[u][j] = lut_pair(lr, j);
+        b.s[u] = p0[u * stride];
+    }
+}
+template <int KC>
+__device__ __forceinline__ void mac_blk1(Acc1<KC>& acc, const Blk1<KC>& b) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const v2f s = v2f{b.s[u], b.s[u]};
+#pragma unroll
+        for (int j = 0; j < KC / 4; j++) {
+            const v2f p = s * b.l[u][j];
+            acc.lo[j] = acc.lo[j] + p;
+            acc.hi[j] = (u & 1) ? acc.hi[j] - p : acc.hi[j] + p;  // steps n0 .. n0 + 3, n0 even: odd n subtracts
+        }
+    }
+}
+// MathHelper.inverseDCTHorizontal (MathHelper.java:68-78), the lane's KC outputs of one channel: dest = src[0], then n = 1 .. N-1 in order
+template <int KC, int N>
+__device__ __forceinline__ void idct1d1(Acc1<KC>& acc, cfloatp lut /* row 0, lane group's slice */, const float* p0, int stride) {
+    acc.init(p0[0]);
+    {
+        float s[3];
+        v2f l[3][KC / 4];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const cfloatp lr = lut + u * N;
+#pragma unroll
+            for (int j = 0; j < KC / 4; j++) l[u][j] = lut_pair(lr, j);
+            s[u] = p0[(u + 1) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const v2f sv = v2f{s[u], s[u]};
+#pragma unroll
+            for (int j = 0; j < KC / 4; j++) {
+                const v2f p = sv * l[u][j];
+                acc.lo[j] = acc.lo[j] + p;
+                acc.hi[j] = (u & 1) ? acc.hi[j] + p : acc.hi[j] - p;  // n = u + 1: odd n subtracts
+            }
+        }
+    }
+    Blk1<KC> cur;
+    load_blk1<KC>(cur, lut + 3 * N, N, p0 + 4 * stride, stride);
+#pragma unroll 1
+    for (int n0 = 4; n0 < N; n0 += 4) {
+        Blk1<KC> nxt;
+        if (n0 + 4 < N) load_blk1<KC>(nxt, lut + (n0 + 3) * N, N, p0 + (n0 + 4) * stride, stride);
+        mac_blk1<KC>(acc, cur);
+        cur = nxt;
+    }
+}
+
 // One LLF coefficient (ky, kx) of channel plane lfp (patch origin, stride bw): forwardDCT2D of the DSH x DSW LF patch
 // (MathHelper.java:124-136: rows, then columns) times llfScale (HFCoefficients.java:194-229). Every lane recomputes the
 // row-pass values it needs: same operations in the same order as the reference's shared scratch arrays.
@@ -345,16 +424,25 @@ __host__ __device__ inline uint32_t wg3_geo(int type) {
 // Item gi of the launch: ONE 32-byte record {type, first block, blocks, geometry word, weight offsets of the three channels, 0}
 // of the list finalize_tables built (wg3_item_table) -- one s_load_dwordx8, nothing looked up behind it (r1-r3: a 16-byte
 // record, the weight offsets through DevFrame::woffs behind it, and a walk over the launch's segments when no list was given).
+// r6: the list may hold HOLES (type -2: wg3_item_table gives a workgroup that ends on a 64x64 block fewer items than the others, and a
+// workgroup's list is the positions w, w + G, ... whatever G is): the first record at or behind position gi, in steps of `step`, that
+// is not one; gi is left on it. type -1: none.
 template <int P>
-__device__ __forceinline__ Item item_of(const Wg3Args& a, int gi) {
+__device__ __forceinline__ Item item_of(const Wg3Args& a, int& gi, int step) {
     Item it{-1, 0, 0, 0u, 0};
-    if (gi >= a.total_items) return it;
-    const auto* w = (const __attribute__((address_space(4))) int*)a.items + 8 * gi;
-    it.type = w[0];
-    it.first = w[1];
-    it.nb = w[2];
-    it.geo = (uint32_t)w[3];
-    it.gi = gi;
+    while (gi < a.total_items) {
+        const auto* w = (const __attribute__((address_space(4))) int*)a.items + 8 * gi;
+        const int type = w[0];
+        if (type != -2) {
+            it.type = type;
+            it.first = w[1];
+            it.nb = w[2];
+            it.geo = (uint32_t)w[3];
+            it.gi = gi;
+            break;
+        }
+        gi += step;
+    }
     return it;
 }
 
@@ -449,7 +537,7 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
         }
         raw.kx[j] = raw.kb[j] = 0.0f;
         if (WS > 1) raw.hfm[j] = 1.0f;
-        if (it.type >= 0 && b < it.nb) {
+        if (it.type >= 0 && b < it.nb && !((it.geo >> 14) & 1u)) {  // (bit 14: the item fetches its coefficients itself -- Item64)
             const int cy = (int)((uint32_t)rc.gx[j] & 0xffffu), cx = (int)((uint32_t)rc.gx[j] >> 16);  // DevBlock
             const uint32_t cfl_zero = (uint32_t)rc.gz[j];
             raw.hfm[j] = (float)rc.gw[j];
@@ -732,6 +820,153 @@ __device__ __forceinline__ void special_store(const Wg3Args& a, const Item& it, 
     pre_store();  // the next item's loads have landed; its LF patches are published (the barrier at the end of the item loop follows)
 }
 
+// ---- r6: a 64x64 DCT block (type 18) as an item of the 256-thread launch -- ONE block, worked channel by channel (Y, X, B) on one
+// 64 x 65 LDS image: 16 samples per lane and channel, column pass and row pass with 16 outputs per lane (idct1d1). Until r6 such blocks
+// were a launch of their own (512 threads, 50 KB of LDS, one round of single items = one item's latency: 29 us alone), and in the
+// regime `value` is measured in a second launch per frame costs the stage ~10 us per frame for 5 % of the pixels
+// (profiles/experiments/r6_wg3_special_items_and_dynamic_ab.txt). Nothing of it is prefetched (the item list puts these items last, behind
+// the special 8x8 ones: wg3_item_table); what the generic prefetch delivers for it is the LF patch of its LLF corner (lf_patch) and
+// its block record word (Raw::rowx). Luma is dequantised first and kept in registers for the chroma-from-luma of X and B. Same
+// operations in the same order as Body<64, 64, 18>::dequant / passes of the 512-thread class (HFCoefficients.java:267-319, 146-229;
+// MathHelper.java:96-122).
+struct Item64 {
+    static constexpr int LD = 65, KC = 16;
+
+    // column pass of the channel in the image -> registers -> back in place
+    static __device__ __forceinline__ void column_pass(const DevFrame& f, int tid, float* __restrict__ img) {
+        const cfloatp lut = (cfloatp)(f.lut + lut_off(6));
+        const int col = tid & 63, kc = __builtin_amdgcn_readfirstlane(tid >> 6);
+        Acc1<KC> acc;
+        idct1d1<KC, 64>(acc, lut + kc * (KC / 2), img + col, LD);
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < KC / 2; i++) {
+            img[(kc * (KC / 2) + i) * LD + col] = acc.get(i);
+            img[(63 - kc * (KC / 2) - i) * LD + col] = acc.get(KC - 1 - i);
+        }
+        lds_barrier();
+    }
+    // row pass of the channel in the image -> plane `out`
+    template <typename PreStore>
+    static __device__ __forceinline__ void row_pass(const DevFrame& f, int tid, const float* __restrict__ img, float* __restrict__ out, int cy, int cx,
+                                                    PreStore pre_store) {
+        const cfloatp lut = (cfloatp)(f.lut + lut_off(6));
+        const int row = tid & 63, kc = __builtin_amdgcn_readfirstlane(tid >> 6);
+        Acc1<KC> acc;
+        idct1d1<KC, 64>(acc, lut + kc * (KC / 2), img + row * LD, 1);
+        pre_store();
+        float* olo = out + (int64_t)(cy * 8 + row) * f.width + cx * 8 + kc * (KC / 2);
+        float* ohi = out + (int64_t)(cy * 8 + row) * f.width + cx * 8 + 64 - (kc + 1) * (KC / 2);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; kk += 4) {
+            *reinterpret_cast<float4*>(olo + kk) = make_float4(acc.get(kk), acc.get(kk + 1), acc.get(kk + 2), acc.get(kk + 3));
+            *reinterpret_cast<float4*>(ohi + kk) = make_float4(acc.get(KC / 2 + kk), acc.get(KC / 2 + kk + 1), acc.get(KC / 2 + kk + 2), acc.get(KC / 2 + kk + 3));
+        }
+    }
+
+    // Y and X completely, B up to and including its column pass (its row pass follows the next item's requests: back())
+    static __device__ __forceinline__ void front(const Wg3Args& a, const Item& it, int tid, float* __restrict__ img, const float* __restrict__ qtab, int rowx) {
+        const DevFrame& f = a.f;
+        const float qbn = f.quant_bias_numerator;
+        const auto* brec = (const __attribute__((address_space(4))) int*)a.blocks + 4 * it.first;  // DevBlock {cy | cx << 16, .., cfl_zero, hf_mul}
+        const auto* irec = (const __attribute__((address_space(4))) int*)a.items + 8 * it.gi;
+        const int cy = (int)((uint32_t)brec[0] & 0xffffu), cx = (int)((uint32_t)brec[0] >> 16);
+        (void)rowx;
+        const uint32_t cfl_zero = (uint32_t)brec[2];
+        const int hfmul = brec[3];
+        float sf[3];
+        {
+            const float* sft = qtab + kWg3AuxFloats;
+            if ((unsigned)hfmul < (unsigned)kWg3SfEntries) {
+                sf[0] = sft[hfmul];
+                sf[1] = sft[kWg3SfEntries + hfmul];
+                sf[2] = sft[2 * kWg3SfEntries + hfmul];
+            } else {
+                sf[0] = f.scale_factor[0] / (float)hfmul;
+                sf[1] = f.scale_factor[1] / (float)hfmul;
+                sf[2] = f.scale_factor[2] / (float)hfmul;
+            }
+        }
+        const float* aux = qtab + kWg3QTab;  // [70] cosine LUT of 2, 4, 8 points | [2] | [32] LLF scale | [192] LF patches
+        const int cells_w = f.width >> 3, tw = f.tw;
+        float dyk[16];  // this lane's 16 dequantised luma samples
+#pragma unroll 1
+        for (int ci = 0; ci < 3; ci++) {
+            const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;  // Y first
+            const float* wt = f.weights_t + irec[4 + c];  // TransformType.flip(): square METHOD_DCT
+            const int32_t* cp = f.coeff[c];
+            const float* kt = c == 0 ? f.kx_tab : f.kb_tab;
+            v4i q[4];
+            v4f w[4];
+            float kf[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int g = tid + 256 * j;  // 4-sample group g of the block: row g / 16, columns 4 (g % 16) ..
+                const int n = g >> 4, x4 = (g & 15) << 2;
+                const int py = cy * 8 + n, px = cx * 8 + x4;
+                const int64_t off = (((int64_t)(py >> 3) * cells_w + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));  // coeff_off
+                q[j] = *reinterpret_cast<const v4i*>(cp + off);
+                w[j] = *reinterpret_cast<const v4f*>(wt + g * 4);
+                kf[j] = 0.0f;
+                if (c != 1) {  // chromaFromLuma factor of the group's 64x64 tile, honouring the cache order (DevBlock::cfl_zero)
+                    const int ty = py >> 6, tx = px >> 6;
+                    const int bit = (ty - ((cy * 8) >> 6)) * 5 + (tx - ((cx * 8) >> 6));
+                    if (!((cfl_zero >> bit) & 1u)) kf[j] = kt[ty * tw + tx];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int g = tid + 256 * j;
+                const int n = g >> 4, x4 = (g & 15) << 2;
+                float dq[4];
+                uint32_t big = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t t = (uint32_t)q[j][i] + 64u;
+                    big |= t;
+                    dq[i] = qtab[c * 128 + (t & 127u)];
+                }
+                if (big >= 128u) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int qv = q[j][i];
+                        if ((uint32_t)qv + 64u >= 128u) dq[i] = (float)qv - qbn / (float)qv;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float v;
+                    if (c == 1) {
+                        v = dq[i] * sf[1] * w[j][i];
+                        dyk[4 * j + i] = v;
+                    } else {
+                        v = dq[i] * sf[c] * w[j][i] + kf[j] * dyk[4 * j + i];  // chromaFromLuma (:186-188)
+                    }
+                    if (n < 8 && x4 + i < 8) continue;  // the LLF corner: written below
+                    img[n * LD + x4 + i] = v;
+                }
+            }
+            if (tid < 64) {
+                const int ky = tid >> 3, kx = tid & 7;
+                float v = aux[104 + c * 64 + tid];  // (llf_in_item = 0: the LLF coefficient itself, from the llf planes)
+                if (a.llf_in_item) v = llf_coeff3<8, 8>(aux, aux + 104 + c * 64, 8, ky, kx, aux + 72);
+                img[ky * LD + kx] = v;
+            }
+            lds_barrier();
+            column_pass(f, tid, img);
+            if (ci == 2) return;
+            row_pass(f, tid, img, c == 1 ? a.o1 : a.o0, cy, cx, []() {});
+            lds_barrier();  // every lane has read the image before the next channel's samples overwrite it
+        }
+    }
+    template <typename PreStore>
+    static __device__ __forceinline__ void back(const Wg3Args& a, const Item& it, int tid, const float* __restrict__ img, PreStore pre_store) {
+        const auto* brec = (const __attribute__((address_space(4))) int*)a.blocks + 4 * it.first;
+        const int cy = (int)((uint32_t)brec[0] & 0xffffu), cx = (int)((uint32_t)brec[0] >> 16);
+        row_pass(a.f, tid, img, a.o2, cy, cx, pre_store);
+    }
+};
+
 // type dispatch of the two specialised phases (workgroup-uniform scalar branch)
 template <bool BIG>
 __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int tid, const Raw<Cls<BIG>::NG, Cls<BIG>::WS>& raw, float* img,
@@ -754,6 +989,7 @@ __device__ __forceinline__ void do_dequant(const Wg3Args& a, const Item& it, int
         case 9: Body<8, 32, 9>::dequant(a, it, tid, raw, img, qtab); break;
         case 10: Body<32, 16, 10>::dequant(a, it, tid, raw, img, qtab); break;
         case 11: Body<16, 32, 11>::dequant(a, it, tid, raw, img, qtab); break;
+        case 18: break;  // (Item64::front, behind the barrier)
         default: SpecialBody::dequant(a, it, tid, raw, img, qtab); break;  // (item_of hands out the types of this class only)
         }
     }
@@ -778,7 +1014,14 @@ __device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int 
         case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
+#ifndef JXL_ABL_NO_ITEM64
+        case 18: Item64::back(a, it, tid, img, pre_store); break;
+#endif
+#ifndef JXL_ABL_NO_SPECIAL_ITEMS
         default: special_store(a, it, tid, img, rowx, pre_store); break;  // (item_of hands out the types of this class only)
+#else
+        default: pre_store(); break;
+#endif
         }
     }
 }
@@ -807,8 +1050,8 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
 #ifdef JXL_IDCT_PRIO
     __builtin_amdgcn_s_setprio(JXL_IDCT_PRIO);
 #endif
-    int gi = (int)blockIdx.x;
-    Item cur = item_of<P>(a, gi);
+    int gi = (int)blockIdx.x;  // list position of the item requested last (cur, then nxt, then nn)
+    Item cur = item_of<P>(a, gi, G);
     if (cur.type < 0) return;
     STAMP3_LIFE(0, __builtin_amdgcn_s_memtime());
     float* img = lds;
@@ -831,7 +1074,8 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
     Recs<NG> rc;
     load_recs<T, NG>(a, cur, tid0, rc);
     prefetch<T, NG, WS>(a, cur, tid0, rc, raw);
-    Item nxt = item_of<P>(a, gi + G);
+    gi += G;
+    Item nxt = item_of<P>(a, gi, G);
     load_recs<T, NG>(a, nxt, tid0, rc);
     // "every load issued so far has landed": an empty asm that reads the destination registers makes the compiler place the
     // wait HERE. Used (i) once before the loop -- the first item needs its data anyway, and the loop header then has no load
@@ -876,15 +1120,23 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         // and its stores instead: special_passes.)
         // a special 8x8 item transforms its blocks first (lane = block of one channel, in registers: special_transform); the registers
         // of the item's own requests are dead by now, and those of the next item's are not in use yet
-        if (!BIG && wg3_is_special(cur.type)) {
+#ifndef JXL_ABL_NO_SPECIAL_ITEMS  // (A/B builds: the code of the r6 item kinds compiled out)
+        if (!BIG && __builtin_expect(wg3_is_special(cur.type), 0)) {
             // (the 256-thread class's prefetch leaves the registers of groups outside an item alone, i.e. the old values stay live
             // across the call below: ended here -- 45 v_mov per special item)
             raw = Raw<NG, WS>{};
             special_phase(cur, tid);
         }
+#endif
+#ifndef JXL_ABL_NO_ITEM64
+        if (!BIG && __builtin_expect(cur.type == 18, 0)) {  // a 64x64 block: everything up to its last channel's row pass (Item64)
+            raw = Raw<NG, WS>{};
+            Item64::front(a, cur, tid, img, qtab, rowx);
+        }
+#endif
         prefetch<T, NG, WS>(a, nxt, tid, rc, raw);
         gi += G;
-        const Item nn = item_of<P>(a, gi + G);
+        const Item nn = item_of<P>(a, gi, G);
         load_recs<T, NG>(a, nn, tid, rc);
         STAMP3(3);
         do_passes<BIG>(a, cur, tid, img, it_no, rowx, landed_and_published);
@@ -991,16 +1243,26 @@ bool wg3_special_items() {
     static const bool v = !(getenv("JXL_WG3_SPECIAL") && atoi(getenv("JXL_WG3_SPECIAL")) == 0);
     return v;
 }
-bool wg3_big(int type) { return type == 18 || type == 19 || type == 20; }
+// r6: 64x64 blocks as items of the 256-thread launch (Item64; JXL_WG3_FOLD64=0: in the 512-thread class's own launch, as until r5).
+// The 64x32 / 32x64 types stay in the 512-thread class (a single block of them has fewer columns / rows than a wave has lanes).
+bool wg3_fold64() {
+    static const bool v = !(getenv("JXL_WG3_FOLD64") && atoi(getenv("JXL_WG3_FOLD64")) == 0);
+    return v;
+}
+bool wg3_big(int type) { return (type == 18 && !wg3_fold64()) || type == 19 || type == 20; }
 
 int wg3_grid_cap(bool big) {
-    static const int g_small = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 512;
+    // r6: 768 = three 256-thread workgroups per CU. Until r5 512, so that the 64-point and the special launches fitted beside this one;
+    // with those blocks as items of this launch (one launch per frame) the batch is 1.5-2 % faster on 640-1024 workgroups and a frame alone
+    // 3 % (profiles/experiments/r6_wg3_grid_single_launch.txt)
+    static const int g_small = getenv("JXL_WG3_GRID") ? atoi(getenv("JXL_WG3_GRID")) : 768;
     static const int g_big = getenv("JXL_WG3_GRID_BIG") ? atoi(getenv("JXL_WG3_GRID_BIG")) : 512;
     return big ? g_big : g_small;
 }
 
 int wg3_blocks_per_item(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
+    if (type == 18 && !wg3_big(type)) return 1;  // Item64: one block, channel by channel
     return ((h > w ? h : w) <= 32 ? 2048 : 4096) / (h * w);
 }
 
@@ -1009,6 +1271,7 @@ static int wg3_img_floats(int type) {
     const int h = JXL_TT[type].ph, w = JXL_TT[type].pw;
     const int nb = wg3_blocks_per_item(type);
     if (wg3_is_special(type)) return 3 * nb * 65;  // SpecialBody
+    if (type == 18 && !wg3_big(type)) return 64 * 65;  // Item64: one channel at a time
     const int img0 = h * (w + 1);
     const int img = w >= 32 ? img0 : img0 + ((w - img0 % 32) + 32) % 32;
     return 3 * nb * img;
@@ -1069,6 +1332,7 @@ static float wg3_item_cost(int type) {  // us per 4K frame tiled with the type (
     case 6: case 7: return 67.f;
     case 8: case 9: return 83.f;
     case 10: case 11: return 90.f;
+    case 18: return 330.f;  // (in the 256-thread class: ONE 64x64 block = 4096 positions, channel by channel, nothing prefetched)
     default: return 100.f;
     }
 }
@@ -1089,7 +1353,8 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
     }
     auto emit = [&](const Rec& r) {
         const int pi3 = (int)JXL_TT[r.type].param_index * 3;
-        const int rec[8] = {r.type, r.first, r.nb, (int)wg3_geo(r.type), woffs[pi3], woffs[pi3 + 1], woffs[pi3 + 2], 0};
+        // (geometry bit 14: the item fetches its coefficients itself -- a 64x64 block in the 256-thread class, Item64)
+        const int rec[8] = {r.type, r.first, r.nb, (int)(wg3_geo(r.type) | (r.type == 18 && !wg3_big(18) ? 1u << 14 : 0u)), woffs[pi3], woffs[pi3 + 1], woffs[pi3 + 2], 0};
         out.insert(out.end(), rec, rec + 8);
     };
     if (!spatial) {  // JXL_WG3_SPATIAL=0: the segments' own order, type after type
@@ -1098,55 +1363,91 @@ void wg3_item_table(const DevBlock* hb, int frame_bw, const IdctSegment* segs, i
         return;
     }
     // r6: the special 8x8 items go BEHIND the others (each part in its own spatial order): such an item issues the next item's requests
-    // only after its transform (special_passes), i.e. the item behind it waits for memory -- at the end of the list that item is another
-    // special one or none (a 4K frame of the default mix has about one special item per workgroup)
-    std::stable_partition(recs.begin(), recs.end(), [](const Rec& r) { return !wg3_is_special(r.type); });
-    const size_t n_normal = (size_t)(std::find_if(recs.begin(), recs.end(), [](const Rec& r) { return wg3_is_special(r.type); }) - recs.begin());
+    // only after its transform (wg3_body), i.e. the item behind it waits for memory -- at the end of a workgroup's list that item is
+    // another special one or none (a 4K frame of the default mix has about one special item per workgroup) --, and the 64x64 blocks of
+    // the 256-thread class (Item64: nothing of them is prefetched either) behind those.
+    auto tail_rank = [](const Rec& r) { return wg3_is_special(r.type) ? 1 : (r.type == 18 && !wg3_big(18)) ? 2 : 0; };
+    std::stable_sort(recs.begin(), recs.end(), [&](const Rec& x, const Rec& y) { return tail_rank(x) < tail_rank(y); });
+    const size_t n_normal = (size_t)(std::find_if(recs.begin(), recs.end(), [&](const Rec& r) { return tail_rank(r) > 0; }) - recs.begin());
+    const size_t n_special_end = (size_t)(std::find_if(recs.begin(), recs.end(), [&](const Rec& r) { return tail_rank(r) > 1; }) - recs.begin());
     static const int run = getenv("JXL_WG3_RUN") ? std::max(1, atoi(getenv("JXL_WG3_RUN"))) : 24;
     out.clear();
-    out.reserve(recs.size() * 8);
-    std::vector<const Rec*> lst;
-    lst.reserve(recs.size());
-    for (int part = 0; part < 2; part++) {
-        const size_t r0 = part == 0 ? 0 : n_normal, r1 = part == 0 ? n_normal : recs.size();
+    // per part: the eight queues (one per XCD: workgroup w runs on XCD w % 8) in spatial order, dealt in runs of about one group's items
+    std::vector<const Rec*> q[3][8];
+    for (int part = 0; part < 3; part++) {
+        const size_t r0 = part == 0 ? 0 : part == 1 ? n_normal : n_special_end, r1 = part == 0 ? n_normal : part == 1 ? n_special_end : recs.size();
         std::stable_sort(recs.begin() + (ptrdiff_t)r0, recs.begin() + (ptrdiff_t)r1, [](const Rec& x, const Rec& y) { return x.key < y.key; });
-        std::vector<const Rec*> q[8];
-        for (size_t i = r0; i < r1; i++) q[((i - r0) / (size_t)run) % 8].push_back(&recs[i]);
-        size_t longest = 0;
-        for (auto& v : q) longest = std::max(longest, v.size());
-        for (size_t i = 0; i < longest; i++)
-            for (int x = 0; x < 8; x++)
-                if (i < q[x].size()) lst.push_back(q[x][i]);
+        for (size_t i = r0; i < r1; i++) q[part][((i - r0) / (size_t)(part == 2 ? 1 : run)) % 8].push_back(&recs[i]);
     }
     static const bool balance = !(getenv("JXL_WG3_BALANCE") && atoi(getenv("JXL_WG3_BALANCE")) == 0);
-    const size_t N = lst.size(), G = (size_t)std::max(0, grid);
-    if (balance && G >= 8 && G % 8 == 0 && N > G) {
-        std::vector<float> load(G, 0.0f);
-        std::vector<const Rec*> its;
-        std::vector<int> wgs;
-        const size_t rounds = (N + G - 1) / G;
-        // the last (possibly partial) round first: its positions are fixed to the first workgroups, the full rounds then even out
-        for (size_t rr = 0; rr < rounds; rr++) {
-            const size_t k = rr == 0 ? rounds - 1 : rr - 1;
-            const size_t p0 = k * G, p1 = std::min(N, p0 + G);
-            for (int x = 0; x < 8; x++) {
-                its.clear();
-                wgs.clear();
-                for (size_t p = p0 + x; p < p1; p += 8) {
-                    its.push_back(lst[p]);
-                    wgs.push_back((int)(p - p0));
+    const size_t G = (size_t)std::max(0, grid);
+    if (!(balance && G >= 8 && G % 8 == 0 && recs.size() > G)) {
+        // no grid to balance for: the queues interleaved (position p belongs to queue p % 8 while all eight last), part after part
+        for (int part = 0; part < 3; part++) {
+            size_t longest = 0;
+            for (auto& v : q[part]) longest = std::max(longest, v.size());
+            for (size_t i = 0; i < longest; i++)
+                for (int x = 0; x < 8; x++)
+                    if (i < q[part][x].size()) emit(*q[part][x][i]);
+        }
+        return;
+    }
+    // Balance (r3; r6: explicit lists). A workgroup's list is the positions w, w + G, ...; an item of 32-point blocks costs 1.8 x one
+    // of 8-point blocks and a 64x64 block six times as much. The 64x64 blocks are dealt first (they are LAST in the lists, but on the
+    // account from the start). Then every queue is dealt round by round to the workgroups of its XCD: a round gives one item to every
+    // workgroup that is not more than one 32-point item ahead of the least loaded one -- the costliest item of the round to the one
+    // with the least work so far (r3's rule) --, so that neighbours in the spatial order run at about the same time behind ONE L2,
+    // the workgroups without a 64x64 block differ by at most an item, and the ones with such a block sit rounds out. A list shorter
+    // than the longest ends in holes (type -2: wg3_body's item walk steps over them, whatever grid it is launched on).
+    const size_t Gq = G / 8;
+    std::vector<float> load(G, 0.0f);
+    std::vector<std::vector<const Rec*>> lists[3];
+    for (auto& l : lists) l.assign(G, {});
+    for (int x = 0; x < 8; x++)
+        for (size_t i = 0; i < q[2][x].size(); i++) {
+            const size_t w = (size_t)x + 8 * (i % Gq);
+            lists[2][w].push_back(q[2][x][i]);
+            load[w] += wg3_item_cost(q[2][x][i]->type);
+        }
+    const float slack = wg3_item_cost(5);
+    std::vector<size_t> elig;
+    std::vector<const Rec*> its;
+    for (int x = 0; x < 8; x++)
+        for (int part = 0; part < 2; part++) {
+            const auto& qq = q[part][x];
+            for (size_t pos = 0; pos < qq.size();) {
+                float lo = load[(size_t)x];
+                for (size_t k = 1; k < Gq; k++) lo = std::min(lo, load[(size_t)x + 8 * k]);
+                elig.clear();
+                for (size_t k = 0; k < Gq; k++)
+                    if (load[(size_t)x + 8 * k] <= lo + slack) elig.push_back((size_t)x + 8 * k);
+                std::stable_sort(elig.begin(), elig.end(), [&](size_t u, size_t v) { return load[u] < load[v]; });
+                const size_t m = std::min(elig.size(), qq.size() - pos);
+                its.assign(qq.begin() + (ptrdiff_t)pos, qq.begin() + (ptrdiff_t)(pos + m));
+                std::stable_sort(its.begin(), its.end(), [](const Rec* u, const Rec* v) { return wg3_item_cost(u->type) > wg3_item_cost(v->type); });
+                for (size_t i = 0; i < m; i++) {
+                    lists[part][elig[i]].push_back(its[i]);
+                    load[elig[i]] += wg3_item_cost(its[i]->type);
                 }
-                std::stable_sort(its.begin(), its.end(), [](const Rec* a, const Rec* b) { return wg3_item_cost(a->type) > wg3_item_cost(b->type); });
-                std::stable_sort(wgs.begin(), wgs.end(), [&](int a, int b) { return load[a] < load[b]; });
-                for (size_t i = 0; i < its.size(); i++) {
-                    lst[p0 + wgs[i]] = its[i];
-                    load[wgs[i]] += wg3_item_cost(its[i]->type);
-                }
+                pos += m;
             }
         }
+    size_t rounds = 0;
+    for (size_t w = 0; w < G; w++) rounds = std::max(rounds, lists[0][w].size() + lists[1][w].size() + lists[2][w].size());
+    out.assign(rounds * G * 8, 0);
+    for (size_t i = 0; i < rounds * G; i++) out[i * 8] = -2;  // holes
+    for (size_t w = 0; w < G; w++) {
+        size_t k = 0;
+        for (int part = 0; part < 3; part++)
+            for (const Rec* r : lists[part][w]) {
+                const int pi3 = (int)JXL_TT[r->type].param_index * 3;
+                const int rec[8] = {r->type, r->first, r->nb, (int)(wg3_geo(r->type) | (r->type == 18 && !wg3_big(18) ? 1u << 14 : 0u)), woffs[pi3], woffs[pi3 + 1], woffs[pi3 + 2], 0};
+                std::copy(rec, rec + 8, out.begin() + (ptrdiff_t)((k * G + w) * 8));
+                k++;
+            }
     }
-    for (const Rec* r : lst) emit(*r);
 }
+
 
 // LLF coefficients of the class's blocks into the llf planes (must precede launch_idct_wg3 on the same stream)
 void launch_llf_wg3(const Wg3Args& a, float* const llf[3], hipStream_t s) {
