@@ -380,7 +380,18 @@ def main():
     for _ in range(32):
         frames[0].run()
     ctxs[0].synchronize()
-    ms_all, ms_idct, ms_rest = stage_ms()
+    ms_all, ms_idct, ms_rest_stage = stage_ms()
+    # r6: the dominant kernel's OWN start -> stop (events recorded by the launch itself: what rocprofv3 reports for it). The stage's
+    # stream events (ms_rest_stage) also hold the boundary between the IDCT launch and this one -- since the IDCT stage is ONE launch
+    # per frame nothing sits between its end and the stage event any more, and the two figures differ by that boundary (~10 us)
+    ms_rest = ms_rest_stage
+    try:
+        v = C.c_float()
+        ctxs[0].call("jxl_vardct_last_stage_ms", 3, C.byref(v))
+        if v.value > 0:
+            ms_rest = v.value
+    except Exception:
+        pass
     ctxs[0].call("jxl_vardct_enable_stage_timing", 0)
 
     # single-frame latency (one frame alone on the device)
@@ -432,7 +443,7 @@ def main():
         try:
             # the timed batch is over and every figure of it has been read: its contexts (8 frames' planes, 16+ streams on the
             # process's 4 hardware queues) go before the boundary legs create their own -- with them alive the streaming leg
-            # measured 3.0 Gpx/s at 8 contexts against 5.0 in a process of its own (tools/r4_stream_ctx_sweep.sh)
+            # measured 3.0 Gpx/s at 8 contexts against 5.0 in a process of its own (tools/archive/r4_stream_ctx_sweep.sh)
             frames.clear()
             for c in ctxs:
                 c.close()
@@ -475,9 +486,9 @@ def main():
     roofline = {
         "bound": "valu", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": "k_restore_fused (Gab, EPF x%d, XYB%s): HIP events around the launch, frame 0 alone on the device (mean of 32 runs enqueued back to back)"
+        "kernel": "k_restore_fused (Gab, EPF x%d, XYB%s): the launch's own start / stop HIP events (hipExtLaunchKernel), frame 0 alone on the device (mean of 32 runs enqueued back to back)"
                   % (epf_iters, ", PQ + u16" if args.workload == "vardct8k_pq" else ""),
-        "kernel_ms": round(ms_rest, 4), "algorithmic_bytes_per_launch": int(rest_bytes),
+        "kernel_ms": round(ms_rest, 4), "restoration_stage_ms_events": round(ms_rest_stage, 4), "algorithmic_bytes_per_launch": int(rest_bytes),
         "kernel_ms_in_batch": round(ms_rest_b, 4),
         "idct_stage_ms": round(ms_idct, 4), "idct_stage_ms_in_batch": round(ms_idct_b, 4), "frame_ms_events": round(ms_all, 4),
         "idct_stage_GBps": round(idct_bytes / (ms_idct * 1e-3) / 1e9, 1) if ms_idct > 0 else None,
@@ -870,7 +881,7 @@ def streaming_leg(_lib, host, d, p, device, npx, ref_out, n_ctx=int(os.environ.g
     if not in_child and not os.environ.get("JXL_BENCH_STREAM_INPROC"):
         # a process of its own: eight contexts and their streams share the runtime's hardware queues -- 4 by default, and a table
         # copy or an IDCT launch of one context then waits behind the other contexts' bus transfers (begin_frame 1.5-3.8 ms per
-        # call; tools/r5_stream_sections.sh). GPU_MAX_HW_QUEUES is read when the runtime initialises, so the leg that stands for
+        # call; tools/archive/r5_stream_sections.sh). GPU_MAX_HW_QUEUES is read when the runtime initialises, so the leg that stands for
         # a multi-decoder host gets its own process with the setting INTEGRATION.md recommends; the timed step keeps the default
         # (it is 1-3 % slower with 16 queues).
         import pickle

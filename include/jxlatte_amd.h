@@ -331,7 +331,9 @@ int32_t    jxl_vardct_out_elem_size(const jxl_ctx* ctx);
 /* number of kernel launches the last jxl_vardct_run enqueued (diagnostics) */
 int32_t    jxl_vardct_last_launch_count(const jxl_ctx* ctx);
 /* HIP-event timing on the ctx stream, averaged over the runs recorded since timing was enabled
- * (ring of the 32 most recent): which = 0 whole run, 1 IDCT stage, 2 restoration+colour stage. */
+ * (ring of the 32 most recent): which = 0 whole run, 1 IDCT stage, 2 restoration+colour stage (from the end of the IDCT stage's last
+ * launch: the boundary between the two launches is inside), 3 the fused restoration kernel's own start -> stop (what a profiler reports
+ * for that launch; JXL_ERR_STATE if the timed runs did not take that kernel). */
 jxl_status jxl_vardct_last_stage_ms(jxl_ctx* ctx, int32_t which, float* ms);
 jxl_status jxl_vardct_enable_stage_timing(jxl_ctx* ctx, int32_t on);
 

@@ -150,7 +150,7 @@ def load():
         try:
             fn = getattr(lib, name)  # AttributeError if the .so does not export it
         except AttributeError:
-            # an A/B run against an OLDER build (JXL_AMD_LIB=..., JXL_AMD_LIB_OLD=1: tools/r4_ab.sh): entries it lacks stay unbound
+            # an A/B run against an OLDER build (JXL_AMD_LIB=..., JXL_AMD_LIB_OLD=1: tools/ab_idct.sh): entries it lacks stay unbound
             if os.environ.get("JXL_AMD_LIB") and os.environ.get("JXL_AMD_LIB_OLD"):
                 continue
             raise

@@ -19,6 +19,9 @@
 #include <limits>
 
 using namespace jxl;
+namespace jxl {
+thread_local hipEvent_t g_restore_kernel_ev[2] = {nullptr, nullptr};  // (stage timing: restore_fused_body.h, launch_tph)
+}
 
 namespace {
 
@@ -197,6 +200,8 @@ struct jxl_ctx {
     bool timing = false;
     static constexpr int kEvSlots = 32;
     hipEvent_t ev[kEvSlots][3] = {};  // ring of (start, after IDCT stage, end) per run
+    hipEvent_t kev[kEvSlots][2] = {}; // ... and the restoration kernel's own start / stop (r6)
+    bool kev_valid = false;           // the last timed run took the single-launch fused restoration kernel
     int ev_runs = 0;                  // runs recorded since timing was enabled
     bool owns_stream = true;
     // fork/join side streams: the per-type IDCT kernels are independent and individually too small to fill
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void k_widen2d_host8(int32_t* __restrict__ pla
 // r5: transfers between page-locked host memory and the device as KERNELS that move 16 bytes per lane through the host buffer's
 // device alias, on a bounded grid. With several contexts streaming frames from several host threads, every hipMemcpyAsync of a frame
 // (the side tables in, the pixels out) held its calling thread for 1.6-2.6 ms -- the runtime's copy path waits on the host for the
-// stream's earlier work -- while a launch returns in microseconds (tools/r5_stream_sections.sh, profiles/r5_stream_*.txt).
+// stream's earlier work -- while a launch returns in microseconds (tools/archive/r5_stream_sections.sh, profiles/r5_stream_*.txt).
 typedef int v4i_cp __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_copy16(const v4i_cp* __restrict__ src, v4i_cp* __restrict__ dst, size_t n16, size_t tail_bytes) {
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -1276,6 +1281,8 @@ jxl_status jxl_ctx_create(int32_t device, jxl_ctx** out) {
     }
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++) (void)hipEventCreate(&c->ev[i][j]);
+    for (int i = 0; i < jxl_ctx::kEvSlots; i++)
+        for (int j = 0; j < 2; j++) (void)hipEventCreate(&c->kev[i][j]);
     (void)hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->llf_ev, hipEventDisableTiming);
     if (const char* e = getenv("JXL_AUX_STREAMS")) c->n_aux = std::max(0, std::min((int)jxl_ctx::kAux, atoi(e)));
@@ -1321,6 +1328,9 @@ void jxl_ctx_destroy(jxl_ctx* c) {
     for (int i = 0; i < jxl_ctx::kEvSlots; i++)
         for (int j = 0; j < 3; j++)
             if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+    for (int i = 0; i < jxl_ctx::kEvSlots; i++)
+        for (int j = 0; j < 2; j++)
+            if (c->kev[i][j]) (void)hipEventDestroy(c->kev[i][j]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->llf_ev) (void)hipEventDestroy(c->llf_ev);
     if (c->batch_ev) (void)hipEventDestroy(c->batch_ev);
@@ -1838,7 +1848,7 @@ static jxl_status commit_i16(jxl_ctx* c, const uint8_t* written, int32_t n_group
         }
         // r4: the widening kernel reads the page-locked planes over PCIe itself -- no SDMA transfer, no device staging copy, one
         // runtime call per plane instead of two. With a dozen contexts committing from a dozen threads the hipMemcpyAsync calls
-        // had become the slowest part of a frame (commit 2-3 ms per frame and thread against 0.06; tools/r4_zerocopy_ab.sh).
+        // had become the slowest part of a frame (commit 2-3 ms per frame and thread against 0.06; tools/archive/r4_zerocopy_ab.sh).
         // JXL_COMMIT_ZEROCOPY=0: the staged form
         if (zc) {
             static const int wgrid_env = getenv("JXL_WIDEN_GRID") ? std::max(1, atoi(getenv("JXL_WIDEN_GRID"))) : 0;
@@ -2129,7 +2139,13 @@ jxl_status run_frame(jxl_ctx* c, bool idct_done, FusedArgs* collect = nullptr, b
                     launch_restore_fused(mids, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rb, s);
             if (fused) launches++;
         } else {
+            if (c->timing) {  // the kernel records its own start / stop (jxl_vardct_last_stage_ms, which = 3)
+                g_restore_kernel_ev[0] = c->kev[c->ev_runs % jxl_ctx::kEvSlots][0];
+                g_restore_kernel_ev[1] = c->kev[c->ev_runs % jxl_ctx::kEvSlots][1];
+            }
             fused = launch_restore_fused(src, dst, c->H, c->W, c->hf_mul.as<int32_t>(), c->sharp.as<int32_t>(), rp, s);
+            g_restore_kernel_ev[0] = g_restore_kernel_ev[1] = nullptr;
+            c->kev_valid = c->timing && fused;
         }
         if (fused) {
             launches++;
@@ -2432,10 +2448,12 @@ jxl_status jxl_vardct_last_stage_ms(jxl_ctx* c, int32_t which, float* ms) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int n = std::min(c->ev_runs, (int)jxl_ctx::kEvSlots);
     const int a = which == 2 ? 1 : 0, b = which == 1 ? 1 : 2;
+    if (which == 3 && !c->kev_valid) return fail(c, JXL_ERR_STATE, "the timed runs did not take the single-launch fused restoration kernel");
     double sum = 0.0;
     for (int i = 0; i < n; i++) {
         float t = 0.0f;
-        HIP_TRY(c, hipEventElapsedTime(&t, c->ev[i][a], c->ev[i][b]));
+        if (which == 3) HIP_TRY(c, hipEventElapsedTime(&t, c->kev[i][0], c->kev[i][1]));  // the kernel's own start -> stop
+        else HIP_TRY(c, hipEventElapsedTime(&t, c->ev[i][a], c->ev[i][b]));
         sum += t;
     }
     *ms = (float)(sum / n);

@@ -215,6 +215,8 @@ struct FusedArgs {
 // false if the configuration is not covered by the fused kernel
 bool fill_restore_fused_args(const float* const in[3], void* const out[3], int h, int w, const int32_t* hf_mul,
                              const int32_t* sharpness, const RestoreParams& p, FusedArgs& a);
+// (stage timing) the events the next single-frame launch of the fused restoration kernel records its own start / stop into; else null
+extern thread_local hipEvent_t g_restore_kernel_ev[2];
 int restore_fused_variant(const FusedArgs& a);  // which kernel instantiation the arguments select
 // the non-float sinks of the fused kernel (k_restore_fused_gen.hip, k_restore_fused_q.hip): one frame (`single`) or a batch
 void launch_restore_fused_gen(const FusedArgs* single, const FusedArgs* host_args, const FusedArgs* dev_args, int n, hipStream_t s);

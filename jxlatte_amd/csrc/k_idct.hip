@@ -153,13 +153,8 @@ __device__ __forceinline__ void small_row(const DevFrame& f, int c, int y, int64
                                           float co[8]) {
     const float qbn = f.quant_bias_numerator;
     auto load8 = [&](int ch, int q[8]) {
-#ifdef JXL_ABL_SPECIAL_NOLOAD  // timing experiment: every lane reads the frame's first rows (always cached)
-        const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + (threadIdx.x & 7) * 64 + y * 8);
-        const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + (threadIdx.x & 7) * 64 + y * 8 + 4);
-#else
         const int4 a = *reinterpret_cast<const int4*>(f.coeff[ch] + base + y * 8);  // (cell-tiled plane: coeff_off)
         const int4 b = *reinterpret_cast<const int4*>(f.coeff[ch] + base + y * 8 + 4);
-#endif
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
     };
     int q[8];
@@ -205,11 +200,7 @@ __device__ __forceinline__ void special_block(const DevFrame& f, const DevBlock 
 #pragma unroll
         for (int y = 0; y < 8; y++) small_row<PI, false>(f, c, y, coeff_off(W, py0, px0), hfm, kc, lf_c, co + y * 8);
         invert_small<TYPE>(co, px);
-#ifdef JXL_ABL_SPECIAL_NOSTORE  // timing experiment: the lanes of a wave store 64 consecutive blocks' worth at the frame's start
-        float* o = (c == 0 ? o0 : c == 1 ? o1 : o2) + (int64_t)(blockIdx.x & 15) * 8 * W + threadIdx.x * 8;
-#else
         float* o = (c == 0 ? o0 : c == 1 ? o1 : o2) + base;
-#endif
 #pragma unroll
         for (int y = 0; y < 8; y++) {
             *reinterpret_cast<float4*>(o + (int64_t)y * W) = make_float4(px[y * 8], px[y * 8 + 1], px[y * 8 + 2], px[y * 8 + 3]);

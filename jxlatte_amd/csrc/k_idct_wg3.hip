@@ -110,9 +110,6 @@ __shared__ unsigned long long g_stamp_lds[24];
 // would be waited for at the next barrier and the software pipeline would collapse (measured: the first version of this
 // kernel was slower than the unpipelined one). Nothing a barrier of this kernel separates goes through global memory.
 __device__ __forceinline__ void lds_barrier() {
-#ifdef JXL_ABL_WG3_NOBAR  // timing experiment (wrong results): the waves of a workgroup never meet
-    return;
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -213,13 +210,8 @@ __device__ __forceinline__ void load_blk(Blk<KC>& b, cfloatp lut /* row n0-1, th
 // steps n0 .. n0+3 (n0 even): even steps add to the mirrored half, odd steps subtract
 template <int KC>
 __device__ __forceinline__ void mac_blk(Acc3<KC>& acc, const Blk<KC>& b) {
-#ifdef JXL_ABL_WG3_NOMAC  // timing experiment (wrong results): one step of four is multiplied and added
-#pragma unroll
-    for (int u = 0; u < 1; u++) {
-#else
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-#endif
         const v2f s[3] = {v2f{b.s[u][0], b.s[u][0]}, v2f{b.s[u][1], b.s[u][1]}, v2f{b.s[u][2], b.s[u][2]}};
 #pragma unroll
         for (int j = 0; j < KC / 4; j++)
@@ -545,11 +537,7 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             // cell-tiled int32 planes (coeff_off): cell (py >> 3, px >> 3), 64 samples each
             const int64_t off = (((int64_t)(py >> 3) * cells_w + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));
 #pragma unroll
-#ifdef JXL_ABL_WG3_NOLOAD  // timing experiment (wrong results): no coefficient is read
-            for (int c = 0; c < 3; c++) raw.q[j][c] = v4i{(int)(off & 3), c, tid & 1, 0};
-#else
             for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const __attribute__((address_space(1))) v4i*>(cp[c] + off);
-#endif
             // chromaFromLuma factors of the tile this group lies in (4 consecutive x from a multiple of 4 never cross a
             // 64-px boundary), honouring the reference's per-group cache order (DevBlock::cfl_zero)
             const int ty = py >> 6, tx = px >> 6;
@@ -724,15 +712,7 @@ struct Body {
             idct1d3<KC, W>(acc, lut_w + kc_row * (KC / 2), r0, r1, r2, 1);
             pre_store();
             STAMP3(7);
-#ifdef JXL_ABL_WG3_NOSTORE  // timing experiment: the outputs are kept alive, nothing is stored
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-#pragma unroll
-                for (int kk = 0; kk < KC; kk++) asm volatile("" ::"v"(acc.get(ch, kk)));
-            if (false) {
-#else
             if (rb < it.nb) {
-#endif
                 float* o3[3] = {a.o0, a.o1, a.o2};
                 const int cy = (int)((uint32_t)rowx & 0xffffu), cx = (int)((uint32_t)rowx >> 16);  // (prefetched with the item: Raw::rowx)
                 const int64_t off = (int64_t)(cy * 8 + ry) * f.width + cx * 8;
@@ -1014,14 +994,8 @@ __device__ __forceinline__ void do_passes(const Wg3Args& a, const Item& it, int 
         case 9: Body<8, 32, 9>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         case 10: Body<32, 16, 10>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
         case 11: Body<16, 32, 11>::passes(a, it, tid, img, it_no, rowx, pre_store); break;
-#ifndef JXL_ABL_NO_ITEM64
         case 18: Item64::back(a, it, tid, img, pre_store); break;
-#endif
-#ifndef JXL_ABL_NO_SPECIAL_ITEMS
         default: special_store(a, it, tid, img, rowx, pre_store); break;  // (item_of hands out the types of this class only)
-#else
-        default: pre_store(); break;
-#endif
         }
     }
 }
@@ -1120,20 +1094,16 @@ __device__ __forceinline__ void wg3_body(const Wg3Args& a) {
         // and its stores instead: special_passes.)
         // a special 8x8 item transforms its blocks first (lane = block of one channel, in registers: special_transform); the registers
         // of the item's own requests are dead by now, and those of the next item's are not in use yet
-#ifndef JXL_ABL_NO_SPECIAL_ITEMS  // (A/B builds: the code of the r6 item kinds compiled out)
         if (!BIG && __builtin_expect(wg3_is_special(cur.type), 0)) {
             // (the 256-thread class's prefetch leaves the registers of groups outside an item alone, i.e. the old values stay live
             // across the call below: ended here -- 45 v_mov per special item)
             raw = Raw<NG, WS>{};
             special_phase(cur, tid);
         }
-#endif
-#ifndef JXL_ABL_NO_ITEM64
         if (!BIG && __builtin_expect(cur.type == 18, 0)) {  // a 64x64 block: everything up to its last channel's row pass (Item64)
             raw = Raw<NG, WS>{};
             Item64::front(a, cur, tid, img, qtab, rowx);
         }
-#endif
         prefetch<T, NG, WS>(a, nxt, tid, rc, raw);
         gi += G;
         const Item nn = item_of<P>(a, gi, G);

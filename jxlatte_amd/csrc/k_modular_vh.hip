@@ -38,7 +38,7 @@
 namespace jxl {
 namespace {
 
-#ifdef JXL_VH_ABL  // timing-only ablations (experiment builds, tools/r5_vh_abl.sh): 1 = no loads, 2 = no stores (zero-size descriptors:
+#ifdef JXL_VH_ABL  // timing-only ablations (experiment builds, tools/archive/r5_vh_abl.sh): 1 = no loads, 2 = no stores (zero-size descriptors:
                    // the range check drops the accesses, the instruction stream stays), set per launch from the environment
 __device__ int g_vh_abl;
 #define VH_ABL(bit) (g_vh_abl & (bit))

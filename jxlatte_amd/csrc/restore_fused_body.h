@@ -30,6 +30,7 @@
 // k_restore_fused_gen.hip (the run-time-generic sink) and k_restore_fused_q.hip (the quantised PNG / u16 sinks), so that the three
 // groups of instantiations compile in parallel.
 #pragma once
+#include <hip/hip_ext.h>  // hipExtLaunchKernelGGL (a launch that records the kernel's own start / stop events)
 #include "jxl_internal.h"
 #include <algorithm>
 #include "restore_sink.h"
@@ -139,12 +140,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
                             hc[py][j] = hc[py][j] + adiff<NW>(nb, u, u + 1, sc);
                         }
                 }
-#ifdef JXL_ABL_NO_NCHAIN  // timing experiment (wrong results): the chain towards the row above is not formed -- what fetching it from
-            // the lane above (its south chain) could save at most, before any exchange cost
-            constexpr int I0 = 1;
-#else
             constexpr int I0 = 0;
-#endif
 #pragma unroll
             for (int i = I0; i <= PH; i++)
 #pragma unroll
@@ -165,11 +161,7 @@ __device__ __forceinline__ void epf_patch(const float* __restrict__ src, int ry,
             for (int px = 0; px < 4; px++) {
                 dist[py * 4 + px][0] = hc[py][px];      // tap (0,-1)
                 dist[py * 4 + px][1] = hc[py][px + 1];  // tap (0,+1)
-#ifdef JXL_ABL_NO_NCHAIN
-                dist[py * 4 + px][2] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((int)threadIdx.x - 8) << 2, __builtin_bit_cast(int, vc[py + 1][px])));
-#else
                 dist[py * 4 + px][2] = vc[py][px];      // tap (-1,0)
-#endif
                 dist[py * 4 + px][3] = vc[py + 1][px];  // tap (+1,0)
             }
     } else {
@@ -460,10 +452,6 @@ struct OutSink {
             colour(o[0][i], o[1][i], o[2][i]);
         }
         const uint32_t g = (uint32_t)(gy * tc.W + gx);
-#ifdef JXL_ABL_NOSTORE  // timing ablation only: the values are computed, (practically) never stored
-        if (o[0][0] != 1.2345e-30f || o[1][1] != 1.2345e-30f || o[2][2] != 1.2345e-30f || o[0][3] != 1.5e-30f || o[1][3] != 1.5e-30f || o[2][0] != 1.5e-30f ||
-            o[0][1] != 1.5e-30f || o[0][2] != 1.5e-30f || o[1][0] != 1.5e-30f || o[1][2] != 1.5e-30f || o[2][1] != 1.5e-30f || o[2][3] != 1.5e-30f) return;
-#endif
         // a whole run of 4 from an even pixel index (tile origins are multiples of 62 px, patch columns of 4, frame widths of 8:
         // g is even for every full run): the kind's wide stores
         if (n == 4 && (g & 1u) == 0 && sink_store4_k<SK>(a, g, o)) return;
@@ -528,14 +516,9 @@ __device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
             if (idx < TOTAL) {
                 const int y = idx / PAIRS, x = (idx - y * PAIRS) * 2;
                 const uint32_t g = base + (uint32_t)(y * W + x);
-#ifdef JXL_ABL_NOLOAD  // timing ablation only (wrong results): no global loads
-                const float fg = (float)(g & 1023u) * 0.001f;
-                const f2a4 v0{fg, fg + 0.5f}, v1{fg * 0.5f, fg}, v2{fg + 0.25f, fg * 2.0f};
-#else
                 const f2a4 v0 = *reinterpret_cast<const f2a4*>(a.in[0] + g);
                 const f2a4 v1 = *reinterpret_cast<const f2a4*>(a.in[1] + g);
                 const f2a4 v2 = *reinterpret_cast<const f2a4*>(a.in[2] + g);
-#endif
                 float* d = A + y * G::SW + x;
                 d[0] = v0.x;
                 d[1] = v0.y;
@@ -692,7 +675,13 @@ void launch_tph(const FusedArgs& a, hipStream_t s) {
     const int tiles_x = (a.W + G::OW - 1) / G::OW, tiles_y = (a.H + G::OH - 1) / G::OH;
     const int n_tiles = tiles_x * tiles_y;
     const dim3 grid(((n_tiles + 7) / 8) * 8);
-    hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, SK, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, a);
+    // stage timing (jxl_vardct_enable_stage_timing): the KERNEL's own start and stop -- what rocprofv3 reports for it -- besides the
+    // stage's events on the stream, which also hold the boundary to the launch in front (r6)
+    if (g_restore_kernel_ev[0] && g_restore_kernel_ev[1])
+        hipExtLaunchKernelGGL((k_restore_fused<GAB, ITERS, SK, PH>), grid, dim3(512 / PH), (uint32_t)(G::LDS_BYTES + pad), s, g_restore_kernel_ev[0],
+                              g_restore_kernel_ev[1], 0u, a);
+    else
+        hipLaunchKernelGGL((k_restore_fused<GAB, ITERS, SK, PH>), grid, dim3(512 / PH), G::LDS_BYTES + pad, s, a);
 }
 
 template <bool GAB, int ITERS, int SK>

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the round's bench figures, each the verbatim JSON line of the named command (GPU box): bash tools/r3_bench_set.sh r3
+# the round's bench figures, each the verbatim JSON line of the named command (GPU box): bash tools/bench_set.sh r3
 R=${1:-r5}
 O=gpurun_out/bench_$R
 mkdir -p $O
