@@ -50,7 +50,10 @@ def parse(argv=None):
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--distinct-frames", type=int, default=8, help="distinct synthetic frames generated per rank (the rest reuse them); default: every frame of the C5 share its own seed 1000 + i (SURVEY 8(d))")
     ap.add_argument("--mix", default="default")
-    ap.add_argument("--stream-groups", type=int, default=0, help="experiment: the frames' contexts share G main streams (0: one per frame)")
+    ap.add_argument("--stream-groups", type=int, default=2,
+                    help="the frames' contexts share G main streams (jxl_ctx_set_stream): frames i, i + G, ... are enqueued behind one another, G frames are "
+                         "in flight (0: one stream per frame -- the default until r5). r6: with the IDCT stage as ONE launch per frame, two frames in flight "
+                         "are 4 % faster than eight (profiles/experiments/r6_stream_groups_prio.txt)")
     ap.add_argument("--size", default="", help="WxH override of the synthetic VarDCT frame size (diagnostics; named in config.workload)")
     ap.add_argument("--epf-iters", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0, help="0 = one HIP stream per frame context (default); 1 = all frames of a rank share one stream")
@@ -278,7 +281,7 @@ def main():
         c = _lib.Context(local_rank)
         if args.streams == 1 and ctxs:
             c.call("jxl_ctx_set_stream", ctxs[0].stream)
-        elif args.stream_groups and i >= args.stream_groups:  # experiment: contexts i, i + G, ... launch on ONE main stream
+        elif args.stream_groups and i >= args.stream_groups:  # contexts i, i + G, ... launch on ONE main stream
             c.call("jxl_ctx_set_stream", ctxs[i % args.stream_groups].stream)
         ctxs.append(c)
         if args.workload == "jxlfile":
@@ -547,7 +550,7 @@ def main():
                                % (args.workload, fpg, W, H, args.mix if distinct else "as coded", epf_iters,
                                   "f32" if out_bytes_px == 12.0 else "PQ u16"),
                    "frames_per_gpu": fpg, "frames_total": n_frames, "frame_seeds": "1000 + i, frame i on rank i mod %d" % world if n_frames > 1 else "1234",
-                   "distinct_frames": len(distinct) or 1, "streams": args.streams if args.streams else fpg,
+                   "distinct_frames": len(distinct) or 1, "streams": 1 if args.streams == 1 else min(fpg, args.stream_groups) if args.stream_groups else fpg,
                    "varblock_area_share": synth.type_histogram(distinct[0]) if distinct else real_stats["varblocks"],
                    "kernel_launches_per_frame": launches,
                    "single_frame_ms": round(single_ms, 4),
