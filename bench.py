@@ -564,7 +564,7 @@ def main():
     if gather:
         line["gather"] = gather
     if (not args.no_also and world == 1 and not use_dist and args.workload == "vardct4k" and args.mix == "default" and args.epf_iters == 2
-            and not args.size and args.stages == 31 and not args.batch):
+            and not args.size and args.stages == 31 and not args.batch and args.frames_per_gpu == 8 and args.streams == 0):
         # the contexts of the headline are released first: the side runs get the device to themselves
         for c in ctxs:
             c.close()

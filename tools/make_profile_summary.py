@@ -50,7 +50,7 @@ dur = durations("sq")
 L = ["# %s -- rocprofv3 summaries (MI355X, gfx950, ROCm 7.2)" % tag, "",
      "Produced by `tools/profile_round.sh %s` on the GPU box + `tools/make_profile_summary.py` (commands inside the script;" % tag,
      "PMC counters in separate runs with --kernel-trace only).", "",
-     "## 1. kernel-trace --stats of the default bench (8 frames/step on 8 streams: kernels of different frames overlap, so these",
+     "## 1. kernel-trace --stats of the default bench (8 frames/step on 2 shared streams -- two frames in flight: kernels of different frames overlap, so these",
      "   averages are LONGER than a kernel alone on the device; bench.py's `roofline.kernel_ms` is the isolated figure)", "",
      "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
 for r in rows:
