@@ -1128,6 +1128,30 @@ __global__ void k_clock_probe(unsigned long long ticks, unsigned long long* out)
         out[1] = r1 - r0;
     }
 }
+// CPU test hook (tests/test_item_table_cpu.py, no device): the item table wg3_item_table builds for a frame whose varblocks are
+// n_blocks[k] blocks of type types[k], laid out type after type in raster order of a frame frame_bw cells wide (positions only feed the
+// spatial sort). out: 8 ints per table position (type, first block, blocks, geometry, 3 weight offsets, 0; type -2 = hole). Returns the
+// number of positions, or -1 if `cap` positions do not hold them.
+extern "C" int jxl_debug_wg3_item_table(const int32_t* types, const int32_t* n_blocks, int n_types, int frame_bw, int grid, int32_t* out, int cap) {
+    std::vector<DevBlock> blocks;
+    std::vector<IdctSegment> segs;
+    int cell = 0;
+    for (int k = 0; k < n_types; k++) {
+        const int t = types[k];
+        if (t < 0 || t >= JXL_NUM_TRANSFORM_TYPES || n_blocks[k] <= 0) return -1;
+        segs.push_back(IdctSegment{t, (int)blocks.size(), n_blocks[k]});
+        const int cw = JXL_TT[t].pw / 8, chh = JXL_TT[t].ph / 8;
+        for (int i = 0; i < n_blocks[k]; i++, cell += cw * chh)
+            blocks.push_back(DevBlock{(uint16_t)((cell / std::max(1, frame_bw)) & 0xffff), (uint16_t)(cell % std::max(1, frame_bw)), (uint32_t)t, 0u, 1});
+    }
+    int32_t woffs[3 * 17] = {};
+    std::vector<int> tab;
+    wg3_item_table(blocks.data(), frame_bw, segs.data(), (int)segs.size(), 0, woffs, true, tab, grid);
+    const int n = (int)(tab.size() / 8);
+    if (n > cap) return -1;
+    std::copy(tab.begin(), tab.end(), out);
+    return n;
+}
 extern "C" int jxl_debug_clock_probe(int device, double us, double* mhz) {
     static hipStream_t s = nullptr;
     static unsigned long long* d = nullptr;
