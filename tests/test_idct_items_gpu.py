@@ -74,11 +74,11 @@ def _types_of(g):
 
 @pytest.mark.parametrize("env", [{"JXL_WG3_SPECIAL": "0"}, {"JXL_WG3_FOLD64": "0"}, {"JXL_WG3_SPECIAL": "0", "JXL_WG3_FOLD64": "0"},
                                  {"JXL_WG3_GRID": "8"}, {"JXL_WG3_GRID": "40"}, {"JXL_WG3_GRID": "2048"}, {"JXL_WG3_BALANCE": "0"},
-                                 {"JXL_WG3_SPATIAL": "0"}])
+                                 {"JXL_WG3_SPATIAL": "0"}, {"JXL_WG3_LLF_IN_ITEM": "0"}, {"JXL_WG3_LLF_IN_ITEM": "0", "JXL_WG3_FOLD64": "0"}])
 def test_switches_give_identical_planes(env, orc):
     """the r5 launch plan (special kernel, 64-point class's own launch), other persistent grids (8: a workgroup walks 1/8 of the frame;
-    40: not a multiple of the number of queues -- no balancing; 2048: more workgroups than can be resident), no balancing, no spatial
-    order: the same bits. The switches are read once per process, hence a process per case."""
+    40: five workgroups per queue; 2048: more workgroups than can be resident), no balancing, no spatial order, finalizeLLF as a launch of
+    its own in front (the items then take their LLF corner from the llf planes): the same bits. The switches are read once per process, hence a process per case."""
     import os
     import subprocess
     import sys
