@@ -537,7 +537,10 @@ __device__ __forceinline__ void prefetch(const Wg3Args& a, const Item& it, int t
             // cell-tiled int32 planes (coeff_off): cell (py >> 3, px >> 3), 64 samples each
             const int64_t off = (((int64_t)(py >> 3) * cells_w + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));
 #pragma unroll
-            for (int c = 0; c < 3; c++) raw.q[j][c] = *reinterpret_cast<const __attribute__((address_space(1))) v4i*>(cp[c] + off);
+            // (r6: non-temporal -- a frame's coefficients are read exactly once; leaving them out of the caches' keep-lists is worth 1-2 %
+            // of the saturated stage and 1.5 % of the batch. The same frame's stage re-run alone, whose 99.5 MB of coefficients would
+            // otherwise come back out of the 256 MB memory-side cache, is 8 % slower for it: profiles/experiments/README.md)
+            for (int c = 0; c < 3; c++) raw.q[j][c] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) v4i*>(cp[c] + off));
             // chromaFromLuma factors of the tile this group lies in (4 consecutive x from a multiple of 4 never cross a
             // 64-px boundary), honouring the reference's per-group cache order (DevBlock::cfl_zero)
             const int ty = py >> 6, tx = px >> 6;
@@ -885,7 +888,7 @@ struct Item64 {
                 const int n = g >> 4, x4 = (g & 15) << 2;
                 const int py = cy * 8 + n, px = cx * 8 + x4;
                 const int64_t off = (((int64_t)(py >> 3) * cells_w + (px >> 3)) << 6) + (((py & 7) << 3) | (px & 7));  // coeff_off
-                q[j] = *reinterpret_cast<const v4i*>(cp + off);
+                q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(cp + off));  // (read once: see prefetch())
                 w[j] = *reinterpret_cast<const v4f*>(wt + g * 4);
                 kf[j] = 0.0f;
                 if (c != 1) {  // chromaFromLuma factor of the group's 64x64 tile, honouring the cache order (DevBlock::cfl_zero)

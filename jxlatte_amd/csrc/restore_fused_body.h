@@ -423,7 +423,7 @@ struct __attribute__((packed, aligned(4))) f2a4 {
 };
 
 // OpsinInverseMatrix.invertXYB + JXLImage.transferInPlace + ImageBuffer.castToInt0 + the global store; SK = sink kind (restore_sink.h)
-template <int SK>
+template <int SK, bool NT = false>
 struct OutSink {
     const FusedArgs& a;
     const TileCtx& tc;
@@ -454,7 +454,7 @@ struct OutSink {
         const uint32_t g = (uint32_t)(gy * tc.W + gx);
         // a whole run of 4 from an even pixel index (tile origins are multiples of 62 px, patch columns of 4, frame widths of 8:
         // g is even for every full run): the kind's wide stores
-        if (n == 4 && (g & 1u) == 0 && sink_store4_k<SK>(a, g, o)) return;
+        if (n == 4 && (g & 1u) == 0 && sink_store4_k<SK, NT>(a, g, o)) return;
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (i < n) sink_store_k<SK>(a, g + i, o[0][i], o[1][i], o[2][i]);
@@ -611,7 +611,7 @@ __device__ __forceinline__ void restore_fused_body(const FusedArgs& a) {
     }
 
     // final sink: XYB + transfer/quantise + global store
-    const OutSink<SK> sink{a, tc};
+    const OutSink<SK, (ITERS != 4)> sink{a, tc};  // (ITERS == 4: the first half of a two-launch run -- its planes are read again at once)
 
     if (ITERS == 0) {
         const int mm = m;

@@ -158,14 +158,24 @@ struct __attribute__((packed, aligned(4))) sink_u4a4 {
     uint32_t x, y, z, w;
 };
 // pixels g .. g+3 of a row, g even, as the kind's wide stores; false: the kind has none (the caller stores pixel by pixel)
-template <int SK>
+// NT (r6): the planes are the frame's final output -- read next by a copy to the host or a collective, not by a kernel of the path --:
+// non-temporal stores (kernel 94.8-99.8 -> 93.6 us, batch +0.6...2.4 %). Not for the first half of a two-launch EPF x 3 run, whose
+// planes the second launch reads at once.
+template <int SK, bool NT = false>
 __device__ __forceinline__ bool sink_store4_k(const FusedArgs& a, uint32_t g, const float o[3][4]) {
     if constexpr (SK == SK_PLAIN) {
         // one 16-byte store per lane and channel: a wave instruction then covers whole rows of 256 contiguous bytes instead of
         // every other 8 bytes (g even: 8-byte aligned, so the store is declared 8-byte aligned; gfx950 global stores do not need
         // 16-byte alignment)
 #pragma unroll
-        for (int c = 0; c < 3; c++) *reinterpret_cast<sink_f4a8*>((float*)a.out[c] + g) = sink_f4a8{o[c][0], o[c][1], o[c][2], o[c][3]};
+        for (int c = 0; c < 3; c++) {
+            if constexpr (NT) {
+                typedef float sink_v4 __attribute__((ext_vector_type(4), aligned(8)));
+                __builtin_nontemporal_store(sink_v4{o[c][0], o[c][1], o[c][2], o[c][3]}, reinterpret_cast<sink_v4*>((float*)a.out[c] + g));
+            } else {
+                *reinterpret_cast<sink_f4a8*>((float*)a.out[c] + g) = sink_f4a8{o[c][0], o[c][1], o[c][2], o[c][3]};
+            }
+        }
         return true;
     } else if constexpr (SK == SK_PQ_U16) {
         // four u16 of a plane = 8 bytes at a 4-byte-aligned address
