@@ -70,3 +70,40 @@ def test_failed_rank_fails_the_run(monkeypatch):
     monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
     assert bench.spawn_ranks(bench.parse(["--gpus", "2"])) == 3
     assert killed == [0]
+
+
+def test_also_runs_are_valid_bench_invocations_and_collect_one_line_each(monkeypatch):
+    """r6: the `also` object of the default line -- every side run is an argument list this script's own parser accepts (a typo there
+    would cost the driver's line its Modular / 8K / EPF figures), never one that would recurse into `also`, and also_runs() keeps the
+    child's value / ms / frac / traffic / cpu_baseline or an `error`, whatever the child does"""
+    import json
+    import bench
+    keys = [k for k, _, _ in bench.ALSO_RUNS]
+    assert keys == ["modular8k", "modular8k_x4", "modular1080p", "vardct8k_pq", "vardct4k_epf1", "vardct4k_epf3"]
+    calls = []
+
+    class R:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout, self.stderr = rc, out, "boom"
+
+    def fake_run(cmd, env=None, capture_output=None, text=None, timeout=None):
+        a = bench.parse(cmd[2:])  # argparse exits on an unknown flag
+        assert a.no_also and a.no_gather and a.no_end_to_end and a.gpus == 1
+        assert "WORLD_SIZE" not in env and "RANK" not in env
+        calls.append(a)
+        if a.workload == "vardct8k_pq":
+            return R(3, "")
+        line = {"value": 1.0, "unit": "Mpixels/s", "ms_per_step": 2.0, "dtype": "int32", "config": {"workload": a.workload},
+                "roofline": {"frac": 0.25, "traffic": 123, "traffic_source": "profiles/x.json"}, "cpu_baseline": {"value": 9.0}}
+        if a.workload == "vardct4k":
+            line["roofline"]["path_frac"] = 0.1
+        return R(0, "noise\n" + json.dumps(line) + "\n")
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    out = bench.also_runs(bench.parse([]))
+    assert len(calls) == 6 and set(keys) <= set(out)
+    assert "error" in out["vardct8k_pq"] and "value" not in out["vardct8k_pq"]
+    assert out["modular8k"]["frac"] == 0.25 and out["modular8k"]["traffic"] == 123 and out["modular8k"]["cpu_baseline"] == {"value": 9.0}
+    assert out["vardct4k_epf1"]["frac"] == 0.1 and out["vardct4k_epf1"]["kernel_frac"] == 0.25
